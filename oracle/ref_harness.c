@@ -1,0 +1,321 @@
+/*
+ * ref_harness.c -- TEST INFRASTRUCTURE, built only where /root/reference exists.
+ *
+ * Glue that drives the REFERENCE's own functions, compiled unmodified from /root/reference by
+ * oracle/Makefile into oracle/_ref/libsvtref.so.  It contains no algorithm: it fills the reference's own
+ * structs (MeContext, PictureParentControlSet, EbPictureBufferDesc ...) from the plain descriptors of
+ * include/svt_hip_me.h, installs the reference's `_c` (or AVX2) kernels into its rtcd pointers and calls
+ * svt_aom_sig_deriv_me / svt_aom_motion_estimation_b64.  Used to pin oracle/me_oracle.c and to generate
+ * tests/golden fixtures; optionally as the "reference" CPU baseline of bench.py.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "definitions.h"
+#include "pcs.h"
+#include "sequence_control_set.h"
+#include "me_context.h"
+#include "me_sb_results.h"
+#include "motion_estimation.h"
+#include "aom_dsp_rtcd.h"
+#include "common_dsp_rtcd.h"
+#include "compute_sad_c.h"
+#include "me_sad_calculation.h"
+#include "enc_mode_config.h"
+
+#include "../include/svt_hip_me.h"
+
+/* AVX2 / SSE4.1 / SSE2 variants (declared in aom_dsp_rtcd.h when ARCH_X86_64) */
+static int g_simd = 0;
+
+/* Installs what svt_aom_setup_rtcd_internal (Codec/aom_dsp_rtcd.c:188, :505-515) would install for the
+ * pointers this path calls: flags == 0 -> `_c`, otherwise the AVX2/SSE4.1/SSE2 picks of that table. */
+void ref_set_simd(int use_avx2) {
+    g_simd = use_avx2;
+#ifdef REF_WITH_AVX2
+    if (use_avx2) {
+        svt_sad_loop_kernel                        = svt_sad_loop_kernel_avx2_intrin;
+        svt_nxm_sad_kernel                         = svt_nxm_sad_kernel_helper_avx2;
+        svt_ext_all_sad_calculation_8x8_16x16      = svt_ext_all_sad_calculation_8x8_16x16_avx2;
+        svt_ext_eight_sad_calculation_32x32_64x64  = svt_ext_eight_sad_calculation_32x32_64x64_avx2;
+        svt_ext_sad_calculation_8x8_16x16          = svt_ext_sad_calculation_8x8_16x16_avx2_intrin;
+        svt_ext_sad_calculation_32x32_64x64        = svt_ext_sad_calculation_32x32_64x64_sse4_intrin;
+        svt_initialize_buffer_32bits               = svt_initialize_buffer_32bits_sse2_intrin;
+        return;
+    }
+#endif
+    svt_sad_loop_kernel                       = svt_sad_loop_kernel_c;
+    svt_nxm_sad_kernel                        = svt_nxm_sad_kernel_helper_c;
+    svt_ext_all_sad_calculation_8x8_16x16     = svt_ext_all_sad_calculation_8x8_16x16_c;
+    svt_ext_eight_sad_calculation_32x32_64x64 = svt_ext_eight_sad_calculation_32x32_64x64_c;
+    svt_ext_sad_calculation_8x8_16x16         = svt_ext_sad_calculation_8x8_16x16_c;
+    svt_ext_sad_calculation_32x32_64x64       = svt_ext_sad_calculation_32x32_64x64_c;
+    svt_initialize_buffer_32bits              = svt_initialize_buffer_32bits_c;
+}
+
+int ref_has_avx2(void) {
+#ifdef REF_WITH_AVX2
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+static void cfg_from_ctx(const MeContext *m, SvtHipMeConfig *c) {
+    memset(c, 0, sizeof(*c));
+    c->hme_search_method      = m->hme_search_method;
+    c->me_search_method       = m->me_search_method;
+    c->enable_hme_flag        = m->enable_hme_flag;
+    c->enable_hme_level0_flag = m->enable_hme_level0_flag;
+    c->enable_hme_level1_flag = m->enable_hme_level1_flag;
+    c->enable_hme_level2_flag = m->enable_hme_level2_flag;
+    c->num_hme_sa_w           = m->num_hme_sa_w;
+    c->num_hme_sa_h           = m->num_hme_sa_h;
+    memcpy(&c->hme_l0_sa, &m->hme_l0_sa, sizeof(c->hme_l0_sa));
+    memcpy(&c->hme_l1_sa, &m->hme_l1_sa, sizeof(c->hme_l1_sa));
+    memcpy(&c->hme_l2_sa, &m->hme_l2_sa, sizeof(c->hme_l2_sa));
+    memcpy(&c->me_sa, &m->me_sa, sizeof(c->me_sa));
+    c->prehme_enable           = m->prehme_ctrl.enable;
+    c->prehme_skip_search_line = m->prehme_ctrl.skip_search_line;
+    c->prehme_l1_early_exit    = m->prehme_ctrl.l1_early_exit;
+    memcpy(c->prehme_sa_cfg, m->prehme_ctrl.prehme_sa_cfg, sizeof(c->prehme_sa_cfg));
+    c->enable_me_hme_ref_pruning               = m->me_hme_prune_ctrls.enable_me_hme_ref_pruning;
+    c->prune_ref_if_hme_sad_dev_bigger_than_th = m->me_hme_prune_ctrls.prune_ref_if_hme_sad_dev_bigger_than_th;
+    c->prune_ref_if_me_sad_dev_bigger_than_th  = m->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th;
+    c->zz_sad_th                               = m->me_hme_prune_ctrls.zz_sad_th;
+    c->zz_sad_pct                              = m->me_hme_prune_ctrls.zz_sad_pct;
+    c->phme_sad_th                             = m->me_hme_prune_ctrls.phme_sad_th;
+    c->phme_sad_pct                            = m->me_hme_prune_ctrls.phme_sad_pct;
+    c->enable_me_sr_adjustment                 = m->me_sr_adjustment_ctrls.enable_me_sr_adjustment;
+    c->reduce_me_sr_based_on_mv_length_th      = m->me_sr_adjustment_ctrls.reduce_me_sr_based_on_mv_length_th;
+    c->stationary_hme_sad_abs_th               = m->me_sr_adjustment_ctrls.stationary_hme_sad_abs_th;
+    c->stationary_me_sr_divisor                = m->me_sr_adjustment_ctrls.stationary_me_sr_divisor;
+    c->reduce_me_sr_based_on_hme_sad_abs_th    = m->me_sr_adjustment_ctrls.reduce_me_sr_based_on_hme_sad_abs_th;
+    c->me_sr_divisor_for_low_hme_sad           = m->me_sr_adjustment_ctrls.me_sr_divisor_for_low_hme_sad;
+    c->distance_based_hme_resizing             = m->me_sr_adjustment_ctrls.distance_based_hme_resizing;
+    c->me_8x8_var_enabled                      = m->me_8x8_var_ctrls.enabled;
+    c->me_sr_div4_th                           = m->me_8x8_var_ctrls.me_sr_div4_th;
+    c->me_sr_div2_th                           = m->me_8x8_var_ctrls.me_sr_div2_th;
+    c->me_sr_mult2_th                          = m->me_8x8_var_ctrls.me_sr_mult2_th;
+    c->mv_sa_adj_enabled                       = m->mv_based_sa_adj.enabled;
+    c->mv_sa_adj_nearest_ref_only              = m->mv_based_sa_adj.nearest_ref_only;
+    c->mv_sa_adj_mv_size_th                    = m->mv_based_sa_adj.mv_size_th;
+    c->mv_sa_adj_sa_multiplier                 = m->mv_based_sa_adj.sa_multiplier;
+    c->prune_me_candidates_th                  = m->prune_me_candidates_th;
+    c->use_best_unipred_cand_only              = m->use_best_unipred_cand_only;
+    c->reduce_hme_l0_sr_th_min                 = m->reduce_hme_l0_sr_th_min;
+    c->reduce_hme_l0_sr_th_max                 = m->reduce_hme_l0_sr_th_max;
+    c->me_early_exit_th                        = m->me_early_exit_th;
+    c->me_safe_limit_zz_th                     = m->me_safe_limit_zz_th;
+    c->prev_me_stage_based_exit_th             = m->prev_me_stage_based_exit_th;
+}
+
+static void ctx_from_cfg(const SvtHipMeConfig *c, MeContext *m) {
+    m->hme_search_method      = c->hme_search_method;
+    m->me_search_method       = c->me_search_method;
+    m->enable_hme_flag        = c->enable_hme_flag;
+    m->enable_hme_level0_flag = c->enable_hme_level0_flag;
+    m->enable_hme_level1_flag = c->enable_hme_level1_flag;
+    m->enable_hme_level2_flag = c->enable_hme_level2_flag;
+    m->num_hme_sa_w           = c->num_hme_sa_w;
+    m->num_hme_sa_h           = c->num_hme_sa_h;
+    memcpy(&m->hme_l0_sa, &c->hme_l0_sa, sizeof(c->hme_l0_sa));
+    memcpy(&m->hme_l1_sa, &c->hme_l1_sa, sizeof(c->hme_l1_sa));
+    memcpy(&m->hme_l2_sa, &c->hme_l2_sa, sizeof(c->hme_l2_sa));
+    memcpy(&m->me_sa, &c->me_sa, sizeof(c->me_sa));
+    m->prehme_ctrl.enable           = c->prehme_enable;
+    m->prehme_ctrl.skip_search_line = c->prehme_skip_search_line;
+    m->prehme_ctrl.l1_early_exit    = c->prehme_l1_early_exit;
+    memcpy(m->prehme_ctrl.prehme_sa_cfg, c->prehme_sa_cfg, sizeof(c->prehme_sa_cfg));
+    m->me_hme_prune_ctrls.enable_me_hme_ref_pruning               = c->enable_me_hme_ref_pruning;
+    m->me_hme_prune_ctrls.prune_ref_if_hme_sad_dev_bigger_than_th = c->prune_ref_if_hme_sad_dev_bigger_than_th;
+    m->me_hme_prune_ctrls.prune_ref_if_me_sad_dev_bigger_than_th  = c->prune_ref_if_me_sad_dev_bigger_than_th;
+    m->me_hme_prune_ctrls.zz_sad_th                               = c->zz_sad_th;
+    m->me_hme_prune_ctrls.zz_sad_pct                              = c->zz_sad_pct;
+    m->me_hme_prune_ctrls.phme_sad_th                             = c->phme_sad_th;
+    m->me_hme_prune_ctrls.phme_sad_pct                            = c->phme_sad_pct;
+    m->me_sr_adjustment_ctrls.enable_me_sr_adjustment             = c->enable_me_sr_adjustment;
+    m->me_sr_adjustment_ctrls.reduce_me_sr_based_on_mv_length_th  = c->reduce_me_sr_based_on_mv_length_th;
+    m->me_sr_adjustment_ctrls.stationary_hme_sad_abs_th           = c->stationary_hme_sad_abs_th;
+    m->me_sr_adjustment_ctrls.stationary_me_sr_divisor            = c->stationary_me_sr_divisor;
+    m->me_sr_adjustment_ctrls.reduce_me_sr_based_on_hme_sad_abs_th = c->reduce_me_sr_based_on_hme_sad_abs_th;
+    m->me_sr_adjustment_ctrls.me_sr_divisor_for_low_hme_sad       = c->me_sr_divisor_for_low_hme_sad;
+    m->me_sr_adjustment_ctrls.distance_based_hme_resizing         = c->distance_based_hme_resizing;
+    m->me_8x8_var_ctrls.enabled                                   = c->me_8x8_var_enabled;
+    m->me_8x8_var_ctrls.me_sr_div4_th                             = c->me_sr_div4_th;
+    m->me_8x8_var_ctrls.me_sr_div2_th                             = c->me_sr_div2_th;
+    m->me_8x8_var_ctrls.me_sr_mult2_th                            = c->me_sr_mult2_th;
+    m->mv_based_sa_adj.enabled                                    = c->mv_sa_adj_enabled;
+    m->mv_based_sa_adj.nearest_ref_only                           = c->mv_sa_adj_nearest_ref_only;
+    m->mv_based_sa_adj.mv_size_th                                 = c->mv_sa_adj_mv_size_th;
+    m->mv_based_sa_adj.sa_multiplier                              = c->mv_sa_adj_sa_multiplier;
+    m->prune_me_candidates_th                                     = c->prune_me_candidates_th;
+    m->use_best_unipred_cand_only                                 = c->use_best_unipred_cand_only;
+    m->reduce_hme_l0_sr_th_min                                    = c->reduce_hme_l0_sr_th_min;
+    m->reduce_hme_l0_sr_th_max                                    = c->reduce_hme_l0_sr_th_max;
+    m->me_early_exit_th                                           = c->me_early_exit_th;
+    m->me_safe_limit_zz_th                                        = c->me_safe_limit_zz_th;
+    m->prev_me_stage_based_exit_th                                = c->prev_me_stage_based_exit_th;
+}
+
+/* Runs the reference's svt_aom_sig_deriv_me (enc_mode_config.c:681) on a pcs/scs that carry only the
+ * inputs that function reads.  The four HME enable flags are set as svt_aom_sig_deriv_multi_processes
+ * sets them (enc_mode_config.c:1634-1645) -- that function is not callable on a bare pcs. */
+int ref_me_config_from_preset(const SvtHipMePresetDesc *p, SvtHipMeConfig *cfg) {
+    SequenceControlSet      *scs = calloc(1, sizeof(*scs));
+    PictureParentControlSet *pcs = calloc(1, sizeof(*pcs));
+    MeContext               *m   = calloc(1, sizeof(*m));
+    if (!scs || !pcs || !m)
+        return 1;
+    scs->static_config.pred_structure = p->rtc_tune ? SVT_AV1_PRED_LOW_DELAY_B : SVT_AV1_PRED_RANDOM_ACCESS;
+    scs->static_config.qp             = p->qp;
+    scs->input_resolution             = (EbInputResolution)p->input_resolution;
+    scs->frame_rate                   = p->frame_rate_q16;
+    scs->mrp_ctrls.safe_limit_nref    = p->safe_limit_nref;
+    scs->mrp_ctrls.safe_limit_zz_th   = p->safe_limit_zz_th;
+    pcs->scs                          = scs;
+    pcs->enc_mode                     = (EncMode)p->enc_mode;
+    pcs->sc_class1                    = p->sc_class1;
+    pcs->temporal_layer_index         = p->temporal_layer_index;
+    pcs->hierarchical_levels          = p->hierarchical_levels;
+    pcs->enable_hme_flag              = 1;
+    pcs->enable_hme_level0_flag       = 1;
+    pcs->enable_hme_level1_flag       = 1;
+    pcs->enable_hme_level2_flag       = (p->sc_class1 || p->enc_mode <= ENC_M6) ? 1 : 0;
+    pcs->use_best_me_unipred_cand_only = p->enc_mode <= ENC_M3 ? 0 : 1; /* enc_mode_config.c:1845-1848 */
+    svt_aom_sig_deriv_me(scs, pcs, m);
+    cfg_from_ctx(m, cfg);
+    free(m);
+    free(pcs);
+    free(scs);
+    return 0;
+}
+
+static EbPictureBufferDesc *make_desc(const SvtHipPlaneDesc *p) {
+    EbPictureBufferDesc *d = calloc(1, sizeof(*d));
+    d->buffer_y            = (EbByte)p->buffer_y;
+    d->stride_y            = p->stride_y;
+    d->org_x               = p->org_x;
+    d->org_y               = p->org_y;
+    d->width               = p->width;
+    d->height              = p->height;
+    d->max_width           = p->width;
+    d->max_height          = p->height;
+    return d;
+}
+
+/* The b64 loop of svt_aom_motion_estimation_kernel (me_process.c:174-290) around the reference's own
+ * svt_aom_motion_estimation_b64.  Same argument convention as orc_me_picture. */
+int ref_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, const SvtHipPlaneDesc cur_planes[3],
+                   const SvtHipPlaneDesc ref_planes[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS][3], SvtHipMeResults *res) {
+    ref_set_simd(g_simd);
+    SequenceControlSet      *scs = calloc(1, sizeof(*scs));
+    PictureParentControlSet *pcs = calloc(1, sizeof(*pcs));
+    MeContext               *m   = calloc(1, sizeof(*m));
+    MotionEstimationData    *med = calloc(1, sizeof(*med));
+    const uint32_t w64 = (desc->aligned_width + 63) / 64, h64 = (desc->aligned_height + 63) / 64, nb = w64 * h64;
+    const uint32_t n_pu = svt_hip_me_n_pu(desc->enable_me_16x16, desc->enable_me_8x8);
+    scs->input_resolution     = (EbInputResolution)desc->input_resolution;
+    scs->mrp_ctrls.only_l_bwd = desc->only_l_bwd;
+    scs->b64_size             = 64;
+    pcs->scs                  = scs;
+    pcs->picture_number       = desc->picture_number;
+    pcs->aligned_width        = desc->aligned_width;
+    pcs->aligned_height       = desc->aligned_height;
+    pcs->hierarchical_levels  = desc->hierarchical_levels;
+    pcs->temporal_layer_index = desc->temporal_layer_index;
+    pcs->similar_brightness_refs = desc->similar_brightness_refs;
+    pcs->enable_me_8x8        = desc->enable_me_8x8;
+    pcs->enable_me_16x16      = desc->enable_me_16x16;
+    pcs->max_number_of_pus_per_sb = desc->max_number_of_pus_per_sb;
+    pcs->gm_ctrls.enabled                      = desc->gm_enabled;
+    pcs->gm_ctrls.use_distance_based_active_th = desc->gm_use_distance_based_active_th;
+    pcs->pa_me_data           = med;
+    med->max_cand             = desc->max_cand;
+    med->max_refs             = desc->max_refs;
+    med->max_l0               = desc->max_l0;
+    med->me_results           = calloc(nb, sizeof(MeSbResults *));
+    pcs->b64_geom             = calloc(nb, sizeof(B64Geom));
+    pcs->me_64x64_distortion  = res->me_64x64_distortion;
+    pcs->me_32x32_distortion  = res->me_32x32_distortion;
+    pcs->me_16x16_distortion  = res->me_16x16_distortion;
+    pcs->me_8x8_distortion    = res->me_8x8_distortion;
+    pcs->rc_me_distortion     = res->rc_me_distortion;
+    pcs->me_8x8_cost_variance = res->me_8x8_cost_variance;
+    pcs->stationary_block_present_sb = res->stationary_block_present_sb;
+    pcs->rc_me_allow_gm              = res->rc_me_allow_gm;
+    for (uint32_t b = 0; b < nb; b++) {
+        MeSbResults *r              = calloc(1, sizeof(*r));
+        r->total_me_candidate_index = res->total_me_candidate_index + (size_t)b * n_pu;
+        r->me_mv_array              = (MvCandidate *)(res->me_mv_array + (size_t)b * n_pu * desc->max_refs);
+        r->me_candidate_array       = (MeCandidate *)(res->me_candidate_array + (size_t)b * n_pu * desc->max_cand);
+        med->me_results[b]          = r;
+        B64Geom *g                  = &pcs->b64_geom[b];
+        g->org_x                    = (uint16_t)((b % w64) * 64);
+        g->org_y                    = (uint16_t)((b / w64) * 64);
+        g->width                    = (uint8_t)((desc->aligned_width - g->org_x) < 64 ? desc->aligned_width - g->org_x : 64);
+        g->height                   = (uint8_t)((desc->aligned_height - g->org_y) < 64 ? desc->aligned_height - g->org_y : 64);
+    }
+    ctx_from_cfg(cfg, m);
+    m->me_type               = ME_OPEN_LOOP;
+    m->num_of_list_to_search = desc->num_of_list_to_search;
+    m->num_of_ref_pic_to_search[0] = desc->num_of_ref_pic_to_search[0];
+    m->num_of_ref_pic_to_search[1] = desc->num_of_ref_pic_to_search[1];
+    m->temporal_layer_index  = desc->temporal_layer_index;
+    m->is_ref                = desc->is_ref;
+    EbPictureBufferDesc *cur[3], *refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS][3];
+    memset(refs, 0, sizeof(refs));
+    for (int l = 0; l < 3; l++) cur[l] = make_desc(&cur_planes[l]);
+    for (int li = 0; li < desc->num_of_list_to_search; li++)
+        for (int ri = 0; ri < desc->num_of_ref_pic_to_search[li]; ri++) {
+            for (int l = 0; l < 3; l++) refs[li][ri][l] = make_desc(&ref_planes[li][ri][l]);
+            m->me_ds_ref_array[li][ri].sixteenth_picture_ptr = refs[li][ri][0];
+            m->me_ds_ref_array[li][ri].quarter_picture_ptr   = refs[li][ri][1];
+            m->me_ds_ref_array[li][ri].picture_ptr           = refs[li][ri][2];
+            m->me_ds_ref_array[li][ri].picture_number        = desc->ref_picture_number[li][ri];
+        }
+    const uint32_t row0 = desc->b64_row_start, nrow = desc->b64_row_count ? desc->b64_row_count : h64 - row0;
+    for (uint32_t by = row0; by < row0 + nrow && by < h64; by++)
+        for (uint32_t bx = 0; bx < w64; bx++) {
+            const uint32_t b = bx + by * w64, ox = bx * 64, oy = by * 64;
+            /* me_process.c:183-214 */
+            m->b64_src_ptr    = &cur[2]->buffer_y[(cur[2]->org_y + oy) * cur[2]->stride_y + cur[2]->org_x + ox];
+            m->b64_src_stride = cur[2]->stride_y;
+            m->quarter_b64_buffer = &cur[1]->buffer_y[(cur[1]->org_y + (oy >> 1)) * cur[1]->stride_y + cur[1]->org_x + (ox >> 1)];
+            m->quarter_b64_buffer_stride = cur[1]->stride_y;
+            m->sixteenth_b64_buffer = &cur[0]->buffer_y[(cur[0]->org_y + (oy >> 2)) * cur[0]->stride_y + cur[0]->org_x + (ox >> 2)];
+            m->sixteenth_b64_buffer_stride = cur[0]->stride_y;
+            svt_aom_motion_estimation_b64(pcs, b, ox, oy, m, cur[2]);
+            /* canonical search-level outputs (see SvtHipMeResults) */
+            for (int li = 0; li < 2; li++)
+                for (int ri = 0; ri < 4; ri++) {
+                    const int    live = li < desc->num_of_list_to_search && ri < desc->num_of_ref_pic_to_search[li];
+                    const size_t k    = ((size_t)b * 2 + li) * 4 + ri;
+                    if (res->do_ref) res->do_ref[k] = live ? m->search_results[li][ri].do_ref : 0;
+                    if (res->hme_sc) {
+                        res->hme_sc[2 * k]     = live ? m->search_results[li][ri].hme_sc_x : 0;
+                        res->hme_sc[2 * k + 1] = live ? m->search_results[li][ri].hme_sc_y : 0;
+                    }
+                    if (res->hme_sad) res->hme_sad[k] = live ? (uint32_t)m->search_results[li][ri].hme_sad : 0;
+                    for (int n = 0; n < 85; n++) {
+                        const int ok = live && m->search_results[li][ri].do_ref;
+                        if (res->sb_best_sad) res->sb_best_sad[k * 85 + n] = ok ? m->p_sb_best_sad[li][ri][n] : MAX_SAD_VALUE;
+                        if (res->sb_best_mv) res->sb_best_mv[k * 85 + n] = ok ? m->p_sb_best_mv[li][ri][n] : 0;
+                    }
+                }
+        }
+    for (uint32_t b = 0; b < nb; b++) free(med->me_results[b]);
+    for (int l = 0; l < 3; l++) free(cur[l]);
+    for (int li = 0; li < 2; li++)
+        for (int ri = 0; ri < 4; ri++)
+            for (int l = 0; l < 3; l++) free(refs[li][ri][l]);
+    free(med->me_results);
+    free(pcs->b64_geom);
+    free(med);
+    free(m);
+    free(pcs);
+    free(scs);
+    return 0;
+}
+
+size_t ref_sizeof_me_context(void) { return sizeof(MeContext); }

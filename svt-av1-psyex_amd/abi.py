@@ -1,0 +1,112 @@
+"""ctypes mirror of include/svt_hip_me.h (the C-ABI).  Pure declarations; no compute.
+
+The structures follow the field order of the header exactly; tests/test_abi.py checks the sizes against
+the compiled libraries (``svt_hip_sizeof`` / ``orc_sizeof``).
+"""
+import ctypes as C
+
+MAX_LISTS = 2
+MAX_REFS = 4
+SQUARE_PU_COUNT = 85
+MAX_SAD_VALUE = 128 * 128 * 255
+
+
+class SearchArea(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16)]
+
+
+class SearchAreaMinMax(C.Structure):
+    _fields_ = [("sa_min", SearchArea), ("sa_max", SearchArea)]
+
+
+class MeConfig(C.Structure):
+    _fields_ = [
+        ("hme_search_method", C.c_uint8), ("me_search_method", C.c_uint8),
+        ("enable_hme_flag", C.c_uint8), ("enable_hme_level0_flag", C.c_uint8),
+        ("enable_hme_level1_flag", C.c_uint8), ("enable_hme_level2_flag", C.c_uint8),
+        ("num_hme_sa_w", C.c_uint16), ("num_hme_sa_h", C.c_uint16),
+        ("hme_l0_sa", SearchAreaMinMax), ("hme_l1_sa", SearchArea), ("hme_l2_sa", SearchArea),
+        ("me_sa", SearchAreaMinMax),
+        ("prehme_enable", C.c_uint8), ("prehme_skip_search_line", C.c_uint8), ("prehme_l1_early_exit", C.c_uint8),
+        ("prehme_sa_cfg", SearchAreaMinMax * 2),
+        ("enable_me_hme_ref_pruning", C.c_uint8),
+        ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16), ("prune_ref_if_me_sad_dev_bigger_than_th", C.c_uint16),
+        ("zz_sad_th", C.c_uint32), ("zz_sad_pct", C.c_uint16), ("phme_sad_th", C.c_uint32), ("phme_sad_pct", C.c_uint16),
+        ("enable_me_sr_adjustment", C.c_uint8),
+        ("reduce_me_sr_based_on_mv_length_th", C.c_uint16), ("stationary_hme_sad_abs_th", C.c_uint16),
+        ("stationary_me_sr_divisor", C.c_uint16), ("reduce_me_sr_based_on_hme_sad_abs_th", C.c_uint16),
+        ("me_sr_divisor_for_low_hme_sad", C.c_uint16), ("distance_based_hme_resizing", C.c_uint8),
+        ("me_8x8_var_enabled", C.c_uint8),
+        ("me_sr_div4_th", C.c_uint32), ("me_sr_div2_th", C.c_uint32), ("me_sr_mult2_th", C.c_uint32),
+        ("mv_sa_adj_enabled", C.c_uint8), ("mv_sa_adj_nearest_ref_only", C.c_uint8),
+        ("mv_sa_adj_mv_size_th", C.c_uint16), ("mv_sa_adj_sa_multiplier", C.c_uint16),
+        ("prune_me_candidates_th", C.c_int32), ("use_best_unipred_cand_only", C.c_uint8),
+        ("reduce_hme_l0_sr_th_min", C.c_uint8), ("reduce_hme_l0_sr_th_max", C.c_uint8),
+        ("me_early_exit_th", C.c_uint32), ("me_safe_limit_zz_th", C.c_uint32), ("prev_me_stage_based_exit_th", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        def conv(v):
+            if isinstance(v, C.Structure):
+                return {n: conv(getattr(v, n)) for n, _ in v._fields_}
+            if isinstance(v, C.Array):
+                return [conv(x) for x in v]
+            return int(v)
+        return conv(self)
+
+
+class MePresetDesc(C.Structure):
+    _fields_ = [
+        ("enc_mode", C.c_int8), ("input_resolution", C.c_uint8), ("sc_class1", C.c_uint8), ("rtc_tune", C.c_uint8),
+        ("temporal_layer_index", C.c_uint8), ("hierarchical_levels", C.c_uint8),
+        ("qp", C.c_uint32), ("frame_rate_q16", C.c_uint32), ("safe_limit_nref", C.c_uint8), ("safe_limit_zz_th", C.c_uint32),
+    ]
+
+
+class PlaneDesc(C.Structure):
+    _fields_ = [
+        ("buffer_y", C.c_void_p), ("stride_y", C.c_uint32), ("org_x", C.c_uint16), ("org_y", C.c_uint16),
+        ("width", C.c_uint16), ("height", C.c_uint16),
+    ]
+
+
+class MePictureDesc(C.Structure):
+    _fields_ = [
+        ("picture_number", C.c_uint64), ("aligned_width", C.c_uint16), ("aligned_height", C.c_uint16),
+        ("num_of_list_to_search", C.c_uint8), ("num_of_ref_pic_to_search", C.c_uint8 * MAX_LISTS),
+        ("temporal_layer_index", C.c_uint8), ("hierarchical_levels", C.c_uint8), ("is_ref", C.c_uint8),
+        ("similar_brightness_refs", C.c_uint8), ("enable_me_8x8", C.c_uint8), ("enable_me_16x16", C.c_uint8),
+        ("max_number_of_pus_per_sb", C.c_uint8), ("max_cand", C.c_uint8), ("max_refs", C.c_uint8), ("max_l0", C.c_uint8),
+        ("input_resolution", C.c_uint8), ("only_l_bwd", C.c_uint8), ("gm_enabled", C.c_uint8),
+        ("gm_use_distance_based_active_th", C.c_uint8), ("b64_row_start", C.c_uint16), ("b64_row_count", C.c_uint16),
+        ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
+    ]
+
+
+class MeResults(C.Structure):
+    _fields_ = [
+        ("total_me_candidate_index", C.c_void_p), ("me_mv_array", C.c_void_p), ("me_candidate_array", C.c_void_p),
+        ("me_64x64_distortion", C.c_void_p), ("me_32x32_distortion", C.c_void_p), ("me_16x16_distortion", C.c_void_p),
+        ("me_8x8_distortion", C.c_void_p), ("rc_me_distortion", C.c_void_p), ("me_8x8_cost_variance", C.c_void_p),
+        ("stationary_block_present_sb", C.c_void_p), ("rc_me_allow_gm", C.c_void_p),
+        ("sb_best_sad", C.c_void_p), ("sb_best_mv", C.c_void_p), ("hme_sc", C.c_void_p), ("hme_sad", C.c_void_p),
+        ("do_ref", C.c_void_p),
+    ]
+
+
+# (field, numpy dtype, per-b64 element count as a function of (n_pu, max_refs, max_cand))
+RESULT_FIELDS = [
+    ("total_me_candidate_index", "u1", lambda n, r, c: n),
+    ("me_mv_array", "u4", lambda n, r, c: n * r),
+    ("me_candidate_array", "u1", lambda n, r, c: n * c),
+    ("me_64x64_distortion", "u4", lambda n, r, c: 1), ("me_32x32_distortion", "u4", lambda n, r, c: 1),
+    ("me_16x16_distortion", "u4", lambda n, r, c: 1), ("me_8x8_distortion", "u4", lambda n, r, c: 1),
+    ("rc_me_distortion", "u4", lambda n, r, c: 1), ("me_8x8_cost_variance", "u4", lambda n, r, c: 1),
+    ("stationary_block_present_sb", "u1", lambda n, r, c: 1), ("rc_me_allow_gm", "u1", lambda n, r, c: 1),
+    ("sb_best_sad", "u4", lambda n, r, c: 2 * 4 * 85), ("sb_best_mv", "u4", lambda n, r, c: 2 * 4 * 85),
+    ("hme_sc", "i2", lambda n, r, c: 2 * 4 * 2), ("hme_sad", "u4", lambda n, r, c: 2 * 4), ("do_ref", "u1", lambda n, r, c: 2 * 4),
+]
+
+
+def n_pu(enable_me_16x16, enable_me_8x8):
+    return (85 if enable_me_8x8 else 21) if enable_me_16x16 else 5
