@@ -1,0 +1,33 @@
+// me_kernel.h -- launch-time parameter block of svt_hip_me_b64_kernel (host and device view).
+#ifndef SVT_HIP_ME_KERNEL_H
+#define SVT_HIP_ME_KERNEL_H
+#include <stdint.h>
+#include "../../include/svt_hip_me.h"
+
+#define SVT_HIP_ME_THREADS 256
+#define SVT_HIP_ME_QUEUES 8 /* one b64 band queue per XCD */
+
+// A padded 8-bit luma plane resident in HBM.  `base` is the padded buffer's first byte (buffer_y); it and
+// `stride` are multiples of 16 so every row keeps the same 16-byte phase; 256 bytes of slack follow the last row.
+struct DevPlane {
+    const uint8_t *base;
+    uint32_t       stride;
+    int32_t        org_x, org_y, width, height;
+};
+
+struct DevPyramid {
+    DevPlane lvl[3]; // 0 = sixteenth, 1 = quarter, 2 = full
+};
+
+struct MeKernelParams {
+    SvtHipMeConfig      cfg;
+    SvtHipMePictureDesc desc;
+    DevPyramid          cur;
+    DevPyramid          ref[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS];
+    SvtHipMeResults     res;   // device pointers
+    uint32_t            w64, row0, n_pu;
+    uint32_t            queue_begin[SVT_HIP_ME_QUEUES + 1]; // job index ranges (jobs are band-local b64 raster indices)
+    uint32_t           *queue_head;                         // SVT_HIP_ME_QUEUES counters, zeroed before launch
+};
+
+#endif

@@ -1,0 +1,1292 @@
+// me_kernel.hip -- open-loop motion estimation for one picture on gfx950 (MI355X, CDNA4).
+//
+// One persistent workgroup (256 threads = 4 wave64) owns one 64x64 block (b64) at a time and runs the whole
+// per-block pipeline of svt_aom_motion_estimation_b64 (reference: Source/Lib/Codec/motion_estimation.c:3076-3153)
+// on the device: zero-MV SADs, pre-HME, HME level 0/1/2, search-centre selection, reference pruning, the
+// 8x8-based integer search for 85 square PUs, candidate construction and the per-block distortion scalars.
+//
+// Mapping to the hardware:
+//   * b64 jobs are pulled from eight band queues in HBM (one per XCD; a workgroup drains the queue of the XCD it
+//     runs on first, so neighbouring blocks -- whose search windows overlap -- share that XCD's L2), then steals.
+//   * every search stages its reference window once into LDS with 16-byte coalesced loads; the source block
+//     lives in LDS (HME) or in registers (integer search).
+//   * SADs use v_qsad_pk_u16_u8: one instruction = 4 search positions x 4 pixels; row-subsampled like the
+//     reference (SUB_SAD_SEARCH).  Arg-min keeps the reference's "first minimum in raster order" rule through a
+//     (sad, y, x) lexicographic key, reduced with LDS 64-bit atomic min.
+//   * integer search: wave <-> 4 consecutive search positions, lane <-> one 8x8 PU (quad-tree lane order), 16x16 /
+//     32x32 / 64x64 sums by DPP/shuffle reductions, 85 running bests in registers.
+//   * the data-dependent control logic (search-area sizing, early exits, pruning) is executed by lane 0 between
+//     the parallel phases, on state kept in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "me_kernel.h"
+
+namespace {
+
+constexpr int kThreads  = SVT_HIP_ME_THREADS;
+constexpr int kMaxReq   = 32;    // searches per batch (4 HME regions x 8 refs)
+constexpr int kWinBytes = 32768; // LDS window arena
+constexpr int kNarrowMaxPos = 32; // searches with at most this many positions are split by block row instead
+
+// z_to_raster, motion_estimation.c:2520-2531: n_idx (quad-tree order) -> raster-within-depth PU index
+__device__ const uint8_t c_z_to_raster[85] = {
+    0,  1,  2,  3,  4,  5,  6,  9,  10, 7,  8,  11, 12, 13, 14, 17, 18, 15, 16, 19, 20, 21, 22, 29, 30, 23, 24, 31, 32,
+    37, 38, 45, 46, 39, 40, 47, 48, 25, 26, 33, 34, 27, 28, 35, 36, 41, 42, 49, 50, 43, 44, 51, 52, 53, 54, 61, 62, 55,
+    56, 63, 64, 69, 70, 77, 78, 71, 72, 79, 80, 57, 58, 65, 66, 59, 60, 67, 68, 73, 74, 81, 82, 75, 76, 83, 84};
+// me_idx_85_8x8_to_16x16_conversion / me_idx_16x16_to_parent_32x32_conversion, definitions.h:2613-2632
+__device__ const uint8_t c_8x8_to_16x16[64] = {5,  5,  6,  6,  7,  7,  8,  8,  5,  5,  6,  6,  7,  7,  8,  8,  9,  9,  10, 10, 11, 11,
+                                               12, 12, 9,  9,  10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 13, 13, 14, 14,
+                                               15, 15, 16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 17, 17, 18, 18, 19, 19, 20, 20};
+__device__ const uint8_t c_16x16_to_32x32[16] = {1, 1, 2, 2, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 4, 4};
+
+typedef unsigned long long u64;
+
+struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
+    const uint8_t *win;   // reference sample of search index (0,0), block row 0
+    uint32_t       stride;
+    int16_t        sa_w, sa_h;
+    uint8_t        bw, bh, rs, level; // block width, effective rows, plane rows per block row, source view
+    uint8_t        skip_even, pad0;
+    int16_t        pad1;
+};
+
+struct Tile { // a rectangle of a Req whose window fits the LDS arena
+    uint8_t  req, narrow;
+    int16_t  x0, y0, w, h; // sub-area of the search area
+    uint16_t pitch;        // LDS row pitch in bytes (multiple of 16)
+    uint16_t shift;        // position x0 sits at LDS byte `shift` of a row
+    uint32_t lds_off;      // byte offset in the arena
+    uint32_t rows;         // window rows staged
+    uint32_t item0, nitems, ng;
+};
+
+struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
+    const uint8_t *pix0; // reference sample co-located with the block's top-left, MV (0,0)
+    uint32_t       stride;
+    int16_t        ox, oy, sa_w, sa_h; // search area origin (MV of index (0,0)) and size
+    uint8_t        li, ri, probe, pad;
+};
+
+struct PreHme {
+    uint16_t sa_w, sa_h;
+    int16_t  col, row;
+    uint32_t sad;
+    uint8_t  valid, pad[3];
+};
+
+struct St { // per-block state (subset of MeContext, me_context.h:366-509)
+    uint32_t org_x, org_y, b64_w, b64_h, b64_index;
+    uint32_t zz_sad[2][4];
+    uint32_t sr_divisor[2][4];
+    uint32_t hme_sad_final[2][4];
+    u64      hme_sad64[2][4]; // SearchResults.hme_sad (needs 64 bit after me_prune_ref for pruned refs)
+    int16_t  hme_sc_x[2][4], hme_sc_y[2][4];
+    uint8_t  do_ref[2][4];
+    PreHme   prehme[2][4][2];
+    uint8_t  performed_phme[2][4][2];
+    int16_t  hx[3][2][4][2][2], hy[3][2][4][2][2]; // [level][list][ref][sr_w][sr_h]
+    uint32_t hs[3][2][4][2][2];
+    SvtHipSearchAreaMinMax hme_l0_sa;
+    int16_t  me_cx[2][4], me_cy[2][4];   // integer-search centre (local x/y_search_center of integer_search_b64)
+    uint8_t  ph_req[2][4][2];            // request index + 1 of a pushed search, 0 = none
+    uint8_t  l0_req[2][4];
+    uint8_t  lvl_req[2][4][2][2];
+    uint8_t  c00_req[2][4];
+    // batch machinery
+    int      nreq, ntile, next_req, next_x, next_y, nitems, cur_tw, cur_th;
+    Req      req[kMaxReq];
+    u64      req_key[kMaxReq];
+    Tile     tile[kMaxReq];
+    uint32_t sadbuf[kMaxReq * kNarrowMaxPos];
+    int      nme, nprobe;
+    MeReq    me[8], me_probe[8];
+    u64      wave_best[4][85];
+    uint32_t best_sad[2][4][85];
+    uint32_t best_mv[2][4][85];
+    uint32_t me_dist[85];
+    uint32_t red[8];
+    int      job;
+};
+
+struct Shared {
+    St      st;
+    uint8_t src64[64 * 64];
+    uint8_t src32[32 * 32];
+    uint8_t src16[16 * 16];
+    __attribute__((aligned(16))) uint8_t win[kWinBytes];
+};
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// svt_aom_get_scaled_picture_distance, motion_estimation.c:1239-1243
+__device__ __forceinline__ uint32_t scaled_distance(uint32_t dist) { return (dist * 5) / 8 + ((dist % 8) ? 1 : 0); }
+
+__device__ __forceinline__ uint32_t ref_distance(const MeKernelParams &p, int li, int ri) {
+    long long d = (long long)p.desc.picture_number - (long long)p.desc.ref_picture_number[li][ri];
+    return (uint16_t)(int16_t)(d < 0 ? -d : d);
+}
+
+// "correct the search area if it is not on the reference picture" (motion_estimation.c:838-866, 1585-1627,
+// 1455-1499): the low edge moves the origin only; the high edge moves the origin, then crops the size.
+__device__ __forceinline__ void clip_axis(int org, int &origin, int &size, int pad, int dim) {
+    if (org + origin < -pad) origin = -pad - org;
+    if (org + origin > dim - 1) origin -= (org + origin) - (dim - 1);
+    if (org + origin + size > dim) size = imax(1, size - ((org + origin + size) - dim));
+}
+
+__device__ __forceinline__ const uint8_t *plane_at(const DevPlane &pl, int x, int y) {
+    return pl.base + (long long)(pl.org_y + y) * pl.stride + (pl.org_x + x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched SAD searches
+// ---------------------------------------------------------------------------------------------
+
+// bytes of LDS a tile of w x h positions needs (worst-case 16-byte phase when shift < 0)
+__device__ __forceinline__ uint32_t tile_bytes(const Req &r, int shift, int w, int h) {
+    const int sh = shift < 0 ? 15 : shift;
+    return (uint32_t)(((sh + w - 1 + r.bw + 15) & ~15) + 16) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
+}
+
+// lane 0: cut the pending requests into tiles whose reference windows fit the LDS arena.  Every request is
+// cut on a fixed (cur_tw x cur_th) grid chosen so that any of its tiles fits an empty arena.
+__device__ void plan_tiles(St &st) {
+    uint32_t used = 0, items = 0;
+    int      nt = 0;
+    while (st.next_req < st.nreq && nt < kMaxReq) {
+        const Req &r = st.req[st.next_req];
+        if (st.next_x == 0 && st.next_y == 0) {
+            int tw = r.sa_w, th = r.sa_h;
+            while (th > 1 && tile_bytes(r, -1, tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
+            while (tw > 8 && tile_bytes(r, -1, tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
+            st.cur_tw = tw;
+            st.cur_th = th;
+        }
+        const int x0 = st.next_x, y0 = st.next_y;
+        const int w = imin(st.cur_tw, r.sa_w - x0), h = imin(st.cur_th, r.sa_h - y0);
+        const int shift = (int)((uintptr_t)(r.win + x0) & 15);
+        const uint32_t need = tile_bytes(r, shift, w, h);
+        if (need > kWinBytes - used) break; // flush what is planned; this tile opens the next round
+        Tile &t   = st.tile[nt];
+        t.req     = (uint8_t)st.next_req;
+        t.x0      = (int16_t)x0;
+        t.y0      = (int16_t)y0;
+        t.w       = (int16_t)w;
+        t.h       = (int16_t)h;
+        t.shift   = (uint16_t)shift;
+        t.pitch   = (uint16_t)(((shift + w - 1 + r.bw + 15) & ~15) + 16);
+        t.rows    = (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
+        t.lds_off = used;
+        t.ng      = (uint32_t)((shift & 3) + w + 3) >> 2;
+        t.narrow  = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
+        t.item0   = items;
+        t.nitems  = t.ng * (uint32_t)h * (t.narrow ? r.bh : 1u);
+        items += t.nitems;
+        used += need;
+        nt++;
+        st.next_x = x0 + w;
+        if (st.next_x >= r.sa_w) {
+            st.next_x = 0;
+            st.next_y = y0 + h;
+            if (st.next_y >= r.sa_h) {
+                st.next_y = 0;
+                st.next_req++;
+            }
+        }
+    }
+    st.ntile  = nt;
+    st.nitems = (int)items;
+}
+
+// all threads: copy the tiles' reference windows into the LDS arena with aligned 16-byte loads
+__device__ void stage_tiles(Shared &sh) {
+    const St &st = sh.st;
+    for (int ti = 0; ti < st.ntile; ti++) {
+        const Tile &t = st.tile[ti];
+        const Req  &r = st.req[t.req];
+        const uint8_t *g0 = r.win + t.x0 + (long long)t.y0 * r.stride - t.shift; // 16-byte aligned
+        const int vec_per_row = t.pitch >> 4;
+        const int total       = vec_per_row * (int)t.rows;
+        for (int i = threadIdx.x; i < total; i += kThreads) {
+            const int row = i / vec_per_row, c = i - row * vec_per_row;
+            const uint4 v = *reinterpret_cast<const uint4 *>(g0 + (long long)row * r.stride + c * 16);
+            *reinterpret_cast<uint4 *>(&sh.win[t.lds_off + row * t.pitch + c * 16]) = v;
+        }
+    }
+}
+
+__device__ __forceinline__ const uint8_t *src_view(const Shared &sh, int level) {
+    return level == 2 ? sh.src64 : (level == 1 ? sh.src32 : sh.src16);
+}
+
+// Packed SAD of 4 neighbouring positions over block rows [r0, r1): returns 4 x u32 sums via out[].
+// The block's source rows come from LDS (broadcast reads); the reference rows from the staged window.
+__device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0,
+                                         int r1, uint32_t out[4]) {
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const int nd = bw >> 2;
+    if ((bw & 3) == 0) {
+        u64 acc = 0;
+        int cnt = 0;
+        for (int r = r0; r < r1; r++) {
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * rs * src_pitch);
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
+            uint32_t lo = w[0];
+            for (int j = 0; j < nd; j++) {
+                const uint32_t hi = w[j + 1];
+                acc = __builtin_amdgcn_qsad_pk_u16_u8(((u64)hi << 32) | lo, s[j], acc);
+                lo  = hi;
+            }
+            cnt += nd;
+            if (cnt + nd > 64) { // 64 x 4 x 255 < 65536: flush the packed 16-bit lanes
+                a0 += (uint32_t)(acc & 0xFFFF); a1 += (uint32_t)((acc >> 16) & 0xFFFF);
+                a2 += (uint32_t)((acc >> 32) & 0xFFFF); a3 += (uint32_t)(acc >> 48);
+                acc = 0; cnt = 0;
+            }
+        }
+        a0 += (uint32_t)(acc & 0xFFFF); a1 += (uint32_t)((acc >> 16) & 0xFFFF);
+        a2 += (uint32_t)((acc >> 32) & 0xFFFF); a3 += (uint32_t)(acc >> 48);
+    } else {
+        // widths that are not a multiple of 4 (right-edge blocks of odd picture widths): byte loop
+        for (int r = r0; r < r1; r++) {
+            const uint8_t *s = src + r * rs * src_pitch;
+            const uint8_t *w = wrow0 + r * rs * pitch;
+            for (int c = 0; c < bw; c++) {
+                const int sv = s[c];
+                a0 += (uint32_t)iabs(sv - (int)w[c]);     a1 += (uint32_t)iabs(sv - (int)w[c + 1]);
+                a2 += (uint32_t)iabs(sv - (int)w[c + 2]); a3 += (uint32_t)iabs(sv - (int)w[c + 3]);
+            }
+        }
+    }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+}
+
+__device__ __forceinline__ void lds_min_u64(u64 *addr, u64 v) { atomicMin(addr, v); }
+
+// all threads: evaluate every tile of the current plan
+__device__ void eval_tiles(Shared &sh) {
+    St &st = sh.st;
+    // zero the narrow accumulators
+    for (int ti = 0; ti < st.ntile; ti++) {
+        const Tile &t = st.tile[ti];
+        if (t.narrow)
+            for (int i = threadIdx.x; i < t.w * t.h; i += kThreads) st.sadbuf[ti * kNarrowMaxPos + i] = 0;
+    }
+    __syncthreads();
+    int ti = 0, cur_req = -1;
+    u64 cur_best = ~0ull;
+    for (int it = threadIdx.x; it < st.nitems; it += kThreads) {
+        while (it >= (int)(st.tile[ti].item0 + st.tile[ti].nitems)) ti++;
+        const Tile &t = st.tile[ti];
+        const Req  &r = st.req[t.req];
+        int         k = it - (int)t.item0;
+        int         slice = 0;
+        if (t.narrow) {
+            slice = k % r.bh;
+            k /= r.bh;
+        }
+        const int g = k % (int)t.ng, y = k / (int)t.ng;
+        const int ysearch = t.y0 + y;
+        if (r.skip_even && !(ysearch & 1)) continue;
+        // the quad covers LDS columns col0 .. col0+3 of the tile's rows; tile-relative x = column - shift
+        const int col0 = (t.shift & ~3) + 4 * g;
+        const int xq   = col0 - t.shift;
+        const uint8_t *wrow0 = &sh.win[t.lds_off + y * t.pitch + col0];
+        const uint8_t *src   = src_view(sh, r.level);
+        const int      sp    = (r.level == 2) ? 64 : (r.level == 1 ? 32 : 16);
+        uint32_t       s4[4];
+        if (t.narrow) {
+            quad_sad(src, sp, wrow0, t.pitch, r.rs, r.bw, slice, slice + 1, s4);
+            for (int i = 0; i < 4; i++) {
+                const int x = xq + i;
+                if (x >= 0 && x < t.w) atomicAdd(&st.sadbuf[ti * kNarrowMaxPos + y * t.w + x], s4[i]);
+            }
+        } else {
+            if ((int)t.req != cur_req) {
+                if (cur_best != ~0ull) lds_min_u64(&st.req_key[cur_req], cur_best);
+                cur_req  = t.req;
+                cur_best = ~0ull;
+            }
+            quad_sad(src, sp, wrow0, t.pitch, r.rs, r.bw, 0, r.bh, s4);
+            for (int i = 0; i < 4; i++) {
+                const int x = xq + i;
+                if (x >= 0 && x < t.w) {
+                    const u64 key = ((u64)s4[i] << 32) | ((u64)(uint32_t)ysearch << 16) | (uint32_t)(t.x0 + x);
+                    cur_best = key < cur_best ? key : cur_best;
+                }
+            }
+        }
+    }
+    if (cur_best != ~0ull) lds_min_u64(&st.req_key[cur_req], cur_best);
+    __syncthreads();
+    for (int tj = 0; tj < st.ntile; tj++) {
+        const Tile &t = st.tile[tj];
+        if (!t.narrow) continue;
+        const Req &r = st.req[t.req];
+        for (int i = threadIdx.x; i < t.w * t.h; i += kThreads) {
+            const int y = i / t.w, x = i - y * t.w;
+            if (r.skip_even && !((t.y0 + y) & 1)) continue;
+            const u64 key = ((u64)st.sadbuf[tj * kNarrowMaxPos + i] << 32) | ((u64)(uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + x);
+            lds_min_u64(&st.req_key[t.req], key);
+        }
+    }
+    __syncthreads();
+}
+
+// all threads: run st.req[0 .. nreq) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x),
+// or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.
+__device__ void run_searches(Shared &sh) {
+    St &st = sh.st;
+    if (threadIdx.x == 0) {
+        st.next_req = 0; st.next_x = 0; st.next_y = 0;
+        for (int i = 0; i < st.nreq; i++) st.req_key[i] = (0xffffffull << 32) | 0xffffffffull;
+    }
+    __syncthreads();
+    for (;;) {
+        if (threadIdx.x == 0) plan_tiles(st);
+        __syncthreads();
+        if (st.ntile == 0) break; // uniform: read from LDS after the barrier
+        stage_tiles(sh);
+        __syncthreads();
+        eval_tiles(sh);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t stride, int sa_w, int sa_h, int bw, int bh, int rs,
+                                         int level, int skip) {
+    Req &r      = st.req[st.nreq++];
+    r.win       = win;
+    r.stride    = stride;
+    r.sa_w      = (int16_t)sa_w;
+    r.sa_h      = (int16_t)sa_h;
+    r.bw        = (uint8_t)bw;
+    r.bh        = (uint8_t)bh;
+    r.rs        = (uint8_t)rs;
+    r.level     = (uint8_t)level;
+    r.skip_even = (uint8_t)(skip && bw == 16 && bh <= 16);
+}
+
+// The svt_sad_loop_kernel call made by the HME levels and pre-HME (e.g. motion_estimation.c:891-909)
+__device__ __forceinline__ void push_hme_req(St &st, const MeKernelParams &p, int level, const DevPlane &rp, int org_x, int org_y,
+                                             int bw, int bh, int ox, int oy, int sa_w, int sa_h, int skip) {
+    const int full = (p.cfg.hme_search_method == 1);
+    push_req(st, plane_at(rp, org_x + ox, org_y + oy), rp.stride, sa_w, sa_h, bw, full ? bh : (bh >> 1), full ? 1 : 2, level, skip);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Integer search: 85 square PUs per position
+// ---------------------------------------------------------------------------------------------
+
+// lane -> 8x8 block coordinates in the reference's PU order (quad-tree / Morton): bits x0 y0 x1 y1 x2 y2
+__device__ __forceinline__ void lane_to_blk(int lane, int &bx, int &by) {
+    bx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
+    by = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+}
+
+__device__ __forceinline__ uint32_t dpp_quad_sum(uint32_t v) {
+    // sum over the 4 lanes of a quad, result in all 4 lanes
+    uint32_t t = v + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    return t + (uint32_t)__builtin_amdgcn_mov_dpp((int)t, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t sum16_of_quads(uint32_t v) {
+    // v is uniform inside each quad; returns the sum of the 4 quads of each 16-lane row, in all 16 lanes
+    uint32_t t = v + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true);
+    return t + (uint32_t)__builtin_amdgcn_mov_dpp((int)t, 0x140 /* row_mirror */, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t sum64_of_rows(uint32_t v) {
+    // v uniform inside each 16-lane row; returns the sum of the 4 rows in all lanes
+    uint32_t t = v + (uint32_t)__shfl_xor((int)v, 16, 64);
+    return t + (uint32_t)__shfl_xor((int)t, 32, 64);
+}
+
+__device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
+    const u64 k = ((u64)sad << 32) | ord;
+    best        = k < best ? k : best;
+}
+
+// all threads: integer search for the refs in st.me[0..nme).  `merge` semantics follow the reference: strict
+// `<` against what is already in best_sad (initial MAX_SAD_VALUE, or the probe's result).
+__device__ void run_me_searches(Shared &sh, const MeKernelParams &p, const MeReq *list, int count) {
+    St       &st   = sh.st;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub  = (p.cfg.me_search_method == 0);
+    const int nrow = sub ? 4 : 8, rstep = sub ? 2 : 1;
+    int       bx, by;
+    lane_to_blk(lane, bx, by);
+    // this lane's 8x8 source block (every other row when sub-sampling): 2 dwords per row, in registers
+    uint32_t s[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int row = by * 8 + (k < nrow ? k * rstep : 0);
+        const uint32_t *sp = reinterpret_cast<const uint32_t *>(&sh.src64[row * 64 + bx * 8]);
+        s[k][0] = sp[0];
+        s[k][1] = sp[1];
+    }
+    for (int mi = 0; mi < count; mi++) {
+        const MeReq m = list[mi];
+        u64 b8 = ~0ull, b16 = ~0ull, b32 = ~0ull, b64 = ~0ull;
+        // tile the search area by rows (and columns) so that the window fits the arena
+        const int W = m.sa_w, H = m.sa_h;
+        int       tw = W, th = H;
+        auto wbytes = [&](int ww, int hh) { return (uint32_t)(((15 + ww - 1 + 64 + 15) & ~15) + 8) * (uint32_t)(hh - 1 + 64); };
+        while (th > 1 && wbytes(tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
+        while (tw > 8 && wbytes(tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
+        for (int y0 = 0; y0 < H; y0 += th)
+            for (int x0 = 0; x0 < W; x0 += tw) {
+                const int w = imin(tw, W - x0), h = imin(th, H - y0);
+                const uint8_t *gwin  = m.pix0 + (m.ox + x0) + (long long)(m.oy + y0) * m.stride;
+                const int      shift = (int)((uintptr_t)gwin & 15);
+                // pitch: multiple of 16 bytes and == 8 (mod 32) dwords-wise -> the 8 block rows of a lane column
+                // land on distinct bank groups for the 8-byte reads
+                int pitch = (shift + w - 1 + 64 + 15) & ~15;
+                if (((pitch >> 2) & 7) != 2) pitch += ((2 - ((pitch >> 2) & 7)) & 7) << 2;
+                pitch     = (pitch + 15) & ~15; // keep 16-byte rows (pitch/4 mod 8 == 2 is not reachable with 16B rows: settle for +8 dwords)
+                const int rows        = h - 1 + 64;
+                const int vec_per_row = pitch >> 4;
+                __syncthreads(); // previous tile fully consumed
+                for (int i = threadIdx.x; i < vec_per_row * rows; i += kThreads) {
+                    const int row = i / vec_per_row, c = i - row * vec_per_row;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(gwin - shift + (long long)row * m.stride + c * 16);
+                    *reinterpret_cast<uint4 *>(&sh.win[row * pitch + c * 16]) = v;
+                }
+                __syncthreads();
+                const int ng = ((shift & 3) + w + 3) >> 2;
+                for (int q = wave; q < ng * h; q += 4) {
+                    const int y = q / ng, g = q - y * ng;
+                    const int col0 = (shift & ~3) + 4 * g, xq = col0 - shift;
+                    const uint8_t *wp = &sh.win[(y + by * 8) * pitch + col0 + bx * 8];
+                    u64 acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (k < nrow) {
+                            const uint32_t *wr = reinterpret_cast<const uint32_t *>(wp + k * rstep * pitch);
+                            const uint32_t d0 = wr[0], d1 = wr[1], d2 = wr[2];
+                            acc = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d1 << 32) | d0, s[k][0], acc);
+                            acc = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d2 << 32) | d1, s[k][1], acc);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int x = xq + i;
+                        uint32_t  v8 = (uint32_t)((acc >> (16 * i)) & 0xFFFF);
+                        if (sub) v8 <<= 1;
+                        const uint32_t v16 = dpp_quad_sum(v8);
+                        const uint32_t v32 = sum16_of_quads(v16);
+                        const uint32_t v64 = sum64_of_rows(v32);
+                        if (x >= 0 && x < w) { // wave-uniform
+                            const uint32_t ord = (uint32_t)((y0 + y) * W + (x0 + x));
+                            upd(b8, v8, ord); upd(b16, v16, ord); upd(b32, v32, ord); upd(b64, v64, ord);
+                        }
+                    }
+                }
+            }
+        // per-wave bests -> LDS, PU index in the reference's n_idx order: 0 = 64x64, 1..4, 5..20, 21..84
+        st.wave_best[wave][21 + lane] = b8;
+        if ((lane & 3) == 0) st.wave_best[wave][5 + (lane >> 2)] = b16;
+        if ((lane & 15) == 0) st.wave_best[wave][1 + (lane >> 4)] = b32;
+        if (lane == 0) st.wave_best[wave][0] = b64;
+        __syncthreads();
+        if (threadIdx.x < 85) {
+            const int n = threadIdx.x;
+            u64 k = st.wave_best[0][n];
+            for (int wv = 1; wv < 4; wv++) k = st.wave_best[wv][n] < k ? st.wave_best[wv][n] : k;
+            const uint32_t sad = (uint32_t)(k >> 32);
+            if (k != ~0ull && sad < st.best_sad[m.li][m.ri][n]) {
+                const uint32_t ord = (uint32_t)k;
+                const int      yy = (int)(ord / (uint32_t)W), xx = (int)(ord - (uint32_t)yy * (uint32_t)W);
+                st.best_sad[m.li][m.ri][n] = sad;
+                st.best_mv[m.li][m.ri][n]  = ((uint32_t)(m.oy + yy) << 16) | (uint16_t)(m.ox + xx);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lane-0 control logic (restates the scalar parts of motion_estimation.c; see per-function citations)
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool searched(const MeKernelParams &p, int li) { return p.desc.temporal_layer_index > 0 || li == 0; }
+
+__device__ void set_hme_all(St &st, const MeKernelParams &p, int lvl, int li, int ri, int x, int y, uint32_t sad) {
+    for (int h = 0; h < p.cfg.num_hme_sa_h; h++)
+        for (int w = 0; w < p.cfg.num_hme_sa_w; w++) {
+            st.hx[lvl][li][ri][w][h] = (int16_t)x;
+            st.hy[lvl][li][ri][w][h] = (int16_t)y;
+            st.hs[lvl][li][ri][w][h] = sad;
+        }
+}
+
+// get_hme_l0_search_area, motion_estimation.c:1800-1868
+__device__ void hme_l0_search_area(St &st, const MeKernelParams &p, int li, int ri, uint32_t dist, int &sa_w, int &sa_h) {
+    const SvtHipMeConfig &c = p.cfg;
+    if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) {
+        int is_hor = 1, is_ver = 1, is_still = 0;
+        if (c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max && (li || ri)) {
+            const int mvx = st.hx[0][0][0][0][0], mvy = st.hy[0][0][0][0][0];
+            is_ver   = iabs(mvx) < c.reduce_hme_l0_sr_th_min && iabs(mvy) > c.reduce_hme_l0_sr_th_max;
+            is_hor   = iabs(mvx) > c.reduce_hme_l0_sr_th_max && iabs(mvy) < c.reduce_hme_l0_sr_th_min;
+            is_still = iabs(mvx) < c.reduce_hme_l0_sr_th_min * 3 && iabs(mvy) < c.reduce_hme_l0_sr_th_min * 3;
+        }
+        int xo = is_hor ? 1 : 2, yo = is_ver ? 1 : 2;
+        if (c.enable_me_sr_adjustment == 2 && is_still) xo = yo = 4;
+        st.hme_l0_sa.sa_min.width  = (uint16_t)(st.hme_l0_sa.sa_min.width / (xo + ri));
+        st.hme_l0_sa.sa_min.height = (uint16_t)(st.hme_l0_sa.sa_min.height / (yo + ri));
+        st.hme_l0_sa.sa_max.width  = (uint16_t)(st.hme_l0_sa.sa_max.width / (xo + ri));
+        st.hme_l0_sa.sa_max.height = (uint16_t)(st.hme_l0_sa.sa_max.height / (yo + ri));
+    }
+    const int f = (int)scaled_distance(dist);
+    int       w = (int16_t)(st.hme_l0_sa.sa_min.width / c.num_hme_sa_w);
+    w           = (int16_t)imin(((w * f) + 15) & ~15, ((st.hme_l0_sa.sa_max.width / c.num_hme_sa_w) + 15) & ~15);
+    int h       = (int16_t)(st.hme_l0_sa.sa_min.height / c.num_hme_sa_h);
+    h           = (int16_t)imin(h * f, st.hme_l0_sa.sa_max.height / c.num_hme_sa_h);
+    sa_w        = w;
+    sa_h        = h;
+}
+
+struct HmeGeom { int16_t ox, oy; };
+
+// hme_level_0/1/2 geometry (motion_estimation.c:820-1113): pushes the search and returns its origin
+__device__ HmeGeom push_hme_level(St &st, const MeKernelParams &p, int level, const DevPlane &rp, int org_x, int org_y, int bw, int bh,
+                                  int sa_w, int sa_h, int cx, int cy, int sr_w, int sr_h) {
+    sa_w = (int16_t)((sa_w + 7) & ~7);
+    int pad_w, pad_h, ox, oy;
+    if (level == 2) { pad_w = pad_h = 63; } else { pad_w = rp.org_x - 1; pad_h = rp.org_y - 1; }
+    if (level == 0) {
+        ox = -(int16_t)((sa_w * p.cfg.num_hme_sa_w) >> 1) + (int16_t)(sa_w * sr_w);
+        oy = -(int16_t)((sa_h * p.cfg.num_hme_sa_h) >> 1) + (int16_t)(sa_h * sr_h);
+    } else {
+        ox = -(sa_w >> 1) + cx;
+        oy = -(sa_h >> 1) + cy;
+    }
+    clip_axis(org_x, ox, sa_w, pad_w, rp.width);
+    sa_w = (sa_w < 8) ? sa_w : (sa_w & ~7);
+    clip_axis(org_y, oy, sa_h, pad_h, rp.height);
+    push_hme_req(st, p, level, rp, org_x, org_y, bw, bh, ox, oy, sa_w, sa_h, 0);
+    HmeGeom g = {(int16_t)ox, (int16_t)oy};
+    return g;
+}
+
+__device__ __forceinline__ void key_to_result(u64 key, int full, uint32_t &sad, int &x, int &y) {
+    sad = (uint32_t)(key >> 32);
+    if ((uint32_t)key == 0xffffffffu) { x = 0; y = 0; } // no position evaluated (known divergence)
+    else { y = (int)((key >> 16) & 0xFFFF); x = (int)(key & 0xFFFF); }
+    if (!full) sad *= 2;
+}
+
+// zero-MV style SAD request: svt_nxm_sad_kernel on every other row (get_zz_sad, motion_estimation.c:1667-1689)
+__device__ __forceinline__ void push_zz_req(St &st, const DevPlane &rp, int dx, int dy) {
+    push_req(st, plane_at(rp, (int)st.org_x + dx, (int)st.org_y + dy), rp.stride, 1, 1, (int)st.b64_w, (int)st.b64_h >> 1, 2, 2, 0);
+}
+
+} // namespace
+
+
+// =================================================================================================
+// The kernel
+// =================================================================================================
+extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS)
+svt_hip_me_b64_kernel(const MeKernelParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    Shared &sh = *reinterpret_cast<Shared *>(smem_raw);
+    St     &st = sh.st;
+    const SvtHipMeConfig      &c = p.cfg;
+    const SvtHipMePictureDesc &d = p.desc;
+    const int tid      = threadIdx.x;
+    const int full_hme = (c.hme_search_method == 1);
+    const int nl       = d.num_of_list_to_search;
+
+    // XCD-aware work pull: queue q holds a contiguous band of b64 rows; start with this XCD's own band
+    uint32_t xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7;
+    int queue_probe = 0; // only lane 0's copy is used
+
+    for (;;) {
+        // ---- fetch the next b64 job -----------------------------------------------------------------
+        if (tid == 0) {
+            int job = -1;
+            while (queue_probe < SVT_HIP_ME_QUEUES) {
+                const int      q  = (int)((xcc + queue_probe) & 7);
+                const uint32_t lo = p.queue_begin[q], hi = p.queue_begin[q + 1];
+                if (lo < hi) {
+                    const uint32_t k = atomicAdd(&p.queue_head[q], 1u);
+                    if (lo + k < hi) { job = (int)(lo + k); break; }
+                }
+                queue_probe++;
+            }
+            st.job = job;
+        }
+        __syncthreads();
+        const int job = st.job;
+        if (job < 0) break; // every wave of the workgroup takes this exit together
+        const uint32_t bxi = (uint32_t)job % p.w64, byi = p.row0 + (uint32_t)job / p.w64;
+        const uint32_t b   = bxi + byi * p.w64;
+
+        // ---- block setup (me_process.c:183-214; motion_estimation.c:3090-3105, init_me_hme_data :3010-3071) ---
+        if (tid == 0) {
+            st.b64_index = b;
+            st.org_x = bxi * 64; st.org_y = byi * 64;
+            st.b64_w = (uint32_t)(d.aligned_width - st.org_x) < 64 ? d.aligned_width - st.org_x : 64;
+            st.b64_h = (uint32_t)(d.aligned_height - st.org_y) < 64 ? d.aligned_height - st.org_y : 64;
+            st.hme_l0_sa = c.hme_l0_sa;
+            st.nreq = 0; st.nme = 0; st.nprobe = 0;
+        }
+        for (int i = tid; i < 3 * 2 * 4 * 2 * 2; i += kThreads) { (&st.hx[0][0][0][0][0])[i] = 0; (&st.hy[0][0][0][0][0])[i] = 0; (&st.hs[0][0][0][0][0])[i] = 0; }
+        for (int i = tid; i < 2 * 4 * 85; i += kThreads) { (&st.best_mv[0][0][0])[i] = 0; (&st.best_sad[0][0][0])[i] = SVT_HIP_MAX_SAD_VALUE; }
+        if (tid < 8) {
+            const int li = tid >> 2, ri = tid & 3;
+            st.do_ref[li][ri] = 1; st.hme_sad64[li][ri] = 0xFFFFFFFFull; st.sr_divisor[li][ri] = 1; st.zz_sad[li][ri] = ~0u;
+            st.hme_sc_x[li][ri] = st.hme_sc_y[li][ri] = 0;
+            for (int sri = 0; sri < 2; sri++) {
+                PreHme &ph = st.prehme[li][ri][sri];
+                ph.valid = 0; ph.col = ph.row = 0; ph.sad = 0; ph.sa_w = ph.sa_h = 0;
+                st.performed_phme[li][ri][sri] = 0;
+            }
+        }
+        { // source views -> LDS.  The 64x64 is always loaded whole: the integer search reads all of it
+            const int ox = (int)(bxi * 64), oy = (int)(byi * 64);
+            for (int i = tid; i < 64 * 4; i += kThreads) {
+                const int row = i >> 2, cc = i & 3;
+                uint4 v; memcpy(&v, plane_at(p.cur.lvl[2], ox + cc * 16, oy + row), 16);
+                *reinterpret_cast<uint4 *>(&sh.src64[row * 64 + cc * 16]) = v;
+            }
+            for (int i = tid; i < 32 * 2; i += kThreads) {
+                const int row = i >> 1, cc = i & 1;
+                uint4 v; memcpy(&v, plane_at(p.cur.lvl[1], (ox >> 1) + cc * 16, (oy >> 1) + row), 16);
+                *reinterpret_cast<uint4 *>(&sh.src32[row * 32 + cc * 16]) = v;
+            }
+            for (int i = tid; i < 16; i += kThreads) {
+                uint4 v; memcpy(&v, plane_at(p.cur.lvl[0], ox >> 2, (oy >> 2) + i), 16);
+                *reinterpret_cast<uint4 *>(&sh.src16[i * 16]) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- init_zz_sad (motion_estimation.c:2382-2437) ------------------------------------------------
+        if (c.me_early_exit_th || c.me_safe_limit_zz_th) {
+            if (tid == 0) {
+                st.nreq = 0;
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
+                        if (searched(p, li)) push_zz_req(st, p.ref[li][ri].lvl[2], 0, 0);
+            }
+            __syncthreads();
+            run_searches(sh);
+            if (tid == 0) {
+                uint32_t best = 0xFFFFFFFFu;
+                int      k    = 0;
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
+                        if (searched(p, li)) {
+                            uint32_t z = (uint32_t)(st.req_key[k++] >> 32) << 1;
+                            z = (z * 64 * 64) / (st.b64_w * st.b64_h);
+                            st.zz_sad[li][ri] = z;
+                            best = z < best ? z : best;
+                        }
+                if (d.temporal_layer_index > 0 && best < c.zz_sad_th)
+                    for (int li = 0; li < nl; li++)
+                        for (int ri = 1; ri < d.num_of_ref_pic_to_search[li]; ri++)
+                            if ((uint32_t)((st.zz_sad[li][ri] - best) * 100) > (uint32_t)(c.zz_sad_pct * best)) st.do_ref[li][ri] = 0;
+                if (c.me_safe_limit_zz_th) {
+                    const bool limit = d.hierarchical_levels > 0 && nl == 2 && d.temporal_layer_index >= d.hierarchical_levels &&
+                        d.similar_brightness_refs && st.zz_sad[0][0] < c.me_safe_limit_zz_th && st.zz_sad[1][0] < c.me_safe_limit_zz_th;
+                    if (limit)
+                        for (int li = 0; li < nl; li++)
+                            for (int ri = 1; ri < d.num_of_ref_pic_to_search[li]; ri++) st.do_ref[li][ri] = 0;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- prehme_b64 (motion_estimation.c:1693-1796) ---------------------------------------------------
+        if (c.prehme_enable) {
+            // with l1_early_exit, list 1 looks at list 0's results: one batch per list then
+            const int nbatch = c.prehme_l1_early_exit ? nl : 1;
+            for (int bi = 0; bi < nbatch; bi++) {
+                const int l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
+                if (tid == 0) {
+                    st.nreq = 0;
+                    for (int li = l_lo; li < l_hi; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                            st.ph_req[li][ri][0] = st.ph_req[li][ri][1] = 0;
+                            if (!searched(p, li)) continue;
+                            const uint32_t f = scaled_distance(ref_distance(p, li, ri));
+                            for (int sri = 0; sri < 2; sri++) {
+                                PreHme &ph = st.prehme[li][ri][sri];
+                                // check_prehme_early_exit (:1693-1720)
+                                if (c.me_early_exit_th && st.zz_sad[li][ri] < c.me_early_exit_th) { ph.col = ph.row = 0; ph.sad = 0; ph.valid = 1; continue; }
+                                if (c.prehme_l1_early_exit) {
+                                    const PreHme &q = st.prehme[0][ri][sri];
+                                    if (li == 1 && q.valid && (q.sad < 32 * 32 || (iabs(q.col) < 16 && iabs(q.row) < 16))) {
+                                        ph.col = (int16_t)-q.col; ph.row = (int16_t)-q.row; ph.sad = q.sad; ph.valid = 1; continue;
+                                    }
+                                }
+                                if (!st.do_ref[li][ri]) { ph.col = ph.row = 0; ph.sad = 0xFFFFFFFFu; continue; }
+                                int sa_w = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.width * f), c.prehme_sa_cfg[sri].sa_max.width);
+                                int sa_h = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.height * f), c.prehme_sa_cfg[sri].sa_max.height);
+                                // prehme_core (:1568-1666)
+                                const DevPlane &rp = p.ref[li][ri].lvl[0];
+                                const int ox16 = (int16_t)st.org_x >> 2, oy16 = (int16_t)st.org_y >> 2;
+                                int ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
+                                clip_axis(ox16, ox, sa_w, rp.org_x - 1, rp.width);
+                                clip_axis(oy16, oy, sa_h, rp.org_y - 1, rp.height);
+                                push_hme_req(st, p, 0, rp, ox16, oy16, (int)st.b64_w >> 2, (int)st.b64_h >> 2, ox, oy, sa_w, sa_h, c.prehme_skip_search_line);
+                                st.ph_req[li][ri][sri] = (uint8_t)st.nreq;
+                                ph.col = (int16_t)ox; ph.row = (int16_t)oy; // search origin until the result is folded in
+                                st.performed_phme[li][ri][sri] = 1;
+                            }
+                        }
+                }
+                __syncthreads();
+                run_searches(sh);
+                if (tid == 0) {
+                    for (int li = l_lo; li < l_hi; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
+                            for (int sri = 0; sri < 2; sri++) {
+                                const int k = st.ph_req[li][ri][sri];
+                                if (!k) continue;
+                                PreHme &ph = st.prehme[li][ri][sri];
+                                uint32_t sad; int x, y;
+                                key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
+                                ph.sad = sad;
+                                ph.col = (int16_t)((int16_t)(x + ph.col) * 4);
+                                ph.row = (int16_t)((int16_t)(y + ph.row) * 4);
+                                ph.valid = 1;
+                            }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                uint32_t best_sad = 0xFFFFFFFFu;
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        if (searched(p, li)) {
+                            const uint32_t m = st.prehme[li][ri][0].sad < st.prehme[li][ri][1].sad ? st.prehme[li][ri][0].sad : st.prehme[li][ri][1].sad;
+                            best_sad = m < best_sad ? m : best_sad;
+                        } else {
+                            for (int sri = 0; sri < 2; sri++) {
+                                st.prehme[1][ri][sri].col = (int16_t)-st.prehme[0][ri][sri].col;
+                                st.prehme[1][ri][sri].row = (int16_t)-st.prehme[0][ri][sri].row;
+                                st.prehme[1][ri][sri].sad = st.prehme[0][ri][sri].sad;
+                            }
+                        }
+                    }
+                if (d.temporal_layer_index > 0 && best_sad < c.phme_sad_th)
+                    for (int li = 0; li < nl; li++)
+                        for (int ri = 1; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                            if (!st.do_ref[li][ri]) continue;
+                            const uint32_t m = st.prehme[li][ri][0].sad < st.prehme[li][ri][1].sad ? st.prehme[li][ri][0].sad : st.prehme[li][ri][1].sad;
+                            if ((uint32_t)((m - best_sad) * 100) > (uint32_t)(c.phme_sad_pct * best_sad)) st.do_ref[li][ri] = 0;
+                        }
+            }
+            __syncthreads();
+        }
+
+        if (c.enable_hme_flag) {
+            // ---- hme_level0_b64 (motion_estimation.c:1906-2036) ------------------------------------------
+            if (c.enable_hme_level0_flag) {
+                // get_hme_l0_search_area reads list0/ref0's level-0 result only when both thresholds are set
+                const bool dep    = c.enable_me_sr_adjustment && c.distance_based_hme_resizing && c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max;
+                const int  nbatch = dep ? 2 : 1;
+                for (int bi = 0; bi < nbatch; bi++) {
+                    if (tid == 0) {
+                        st.nreq = 0;
+                        const SvtHipSearchAreaMinMax base = st.hme_l0_sa;
+                        for (int li = 0; li < nl; li++)
+                            for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                                if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
+                                st.l0_req[li][ri] = 0;
+                                if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 0, li, ri, 0, 0, 0); continue; }
+                                if (c.prev_me_stage_based_exit_th) {
+                                    const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
+                                    if (st.performed_phme[li][ri][sri] && st.prehme[li][ri][sri].sad < (c.prev_me_stage_based_exit_th >> 4)) {
+                                        set_hme_all(st, p, 0, li, ri, st.prehme[li][ri][sri].col, st.prehme[li][ri][sri].row, st.prehme[li][ri][sri].sad);
+                                        continue;
+                                    }
+                                }
+                                if (!st.do_ref[li][ri]) { set_hme_all(st, p, 0, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
+                                if (!searched(p, li)) continue;
+                                int sa_w = 0, sa_h = 0;
+                                hme_l0_search_area(st, p, li, ri, ref_distance(p, li, ri), sa_w, sa_h);
+                                st.l0_req[li][ri] = (uint8_t)(st.nreq + 1);
+                                for (int h = 0; h < c.num_hme_sa_h; h++)
+                                    for (int w = 0; w < c.num_hme_sa_w; w++) {
+                                        const HmeGeom g = push_hme_level(st, p, 0, p.ref[li][ri].lvl[0], (int16_t)st.org_x >> 2, (int16_t)st.org_y >> 2,
+                                                                         (int)st.b64_w >> 2, (int)st.b64_h >> 2, sa_w, sa_h, 0, 0, w, h);
+                                        st.hx[0][li][ri][w][h] = g.ox; st.hy[0][li][ri][w][h] = g.oy;
+                                    }
+                                if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) st.hme_l0_sa = base;
+                            }
+                    }
+                    __syncthreads();
+                    run_searches(sh);
+                    if (tid == 0) {
+                        for (int li = 0; li < nl; li++)
+                            for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                                if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
+                                int k = st.l0_req[li][ri];
+                                if (!k) continue;
+                                k--;
+                                for (int h = 0; h < c.num_hme_sa_h; h++)
+                                    for (int w = 0; w < c.num_hme_sa_w; w++, k++) {
+                                        uint32_t sad; int x, y;
+                                        key_to_result(st.req_key[k], full_hme, sad, x, y);
+                                        st.hs[0][li][ri][w][h] = sad;
+                                        st.hx[0][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[0][li][ri][w][h]) * 4);
+                                        st.hy[0][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[0][li][ri][w][h]) * 4);
+                                    }
+                                if (c.prehme_enable) {
+                                    // get_worst_quadrant (:1872-1901): the last compare does not raise the max
+                                    int ww = 0, wh = 0; uint32_t mx = 0;
+                                    if (st.hs[0][li][ri][0][0] > mx) { mx = st.hs[0][li][ri][0][0]; ww = 0; wh = 0; }
+                                    if (st.hs[0][li][ri][1][0] > mx) { mx = st.hs[0][li][ri][1][0]; ww = 1; wh = 0; }
+                                    if (st.hs[0][li][ri][0][1] > mx) { mx = st.hs[0][li][ri][0][1]; ww = 0; wh = 1; }
+                                    if (st.hs[0][li][ri][1][1] > mx) { ww = 1; wh = 1; }
+                                    const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
+                                    if (st.prehme[li][ri][sri].sad < st.hs[0][li][ri][ww][wh]) {
+                                        st.hs[0][li][ri][ww][wh] = st.prehme[li][ri][sri].sad;
+                                        st.hx[0][li][ri][ww][wh] = st.prehme[li][ri][sri].col;
+                                        st.hy[0][li][ri][ww][wh] = st.prehme[li][ri][sri].row;
+                                    }
+                                }
+                            }
+                    }
+                    __syncthreads();
+                }
+            }
+            // ---- hme_level1_b64 / hme_level2_b64 (motion_estimation.c:2041-2177) ----------------------------
+            for (int lvl = 1; lvl <= 2; lvl++) {
+                if (lvl == 1 ? !c.enable_hme_level1_flag : !c.enable_hme_level2_flag) continue;
+                if (tid == 0) {
+                    st.nreq = 0;
+                    for (int i = 0; i < 2 * 4 * 2 * 2; i++) (&st.lvl_req[0][0][0][0])[i] = 0;
+                    for (int li = 0; li < nl; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                            if (!searched(p, li)) continue;
+                            if (lvl == 1) {
+                                if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 1, li, ri, 0, 0, 0); continue; }
+                                if (!st.do_ref[li][ri]) { set_hme_all(st, p, 1, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
+                            }
+                            for (int h = 0; h < c.num_hme_sa_h; h++)
+                                for (int w = 0; w < c.num_hme_sa_w; w++) {
+                                    const uint32_t exit_th = c.prev_me_stage_based_exit_th >> (lvl == 1 ? 5 : 2);
+                                    if (c.prev_me_stage_based_exit_th && st.hs[lvl - 1][li][ri][w][h] < exit_th) {
+                                        st.hx[lvl][li][ri][w][h] = st.hx[lvl - 1][li][ri][w][h];
+                                        st.hy[lvl][li][ri][w][h] = st.hy[lvl - 1][li][ri][w][h];
+                                        st.hs[lvl][li][ri][w][h] = st.hs[lvl - 1][li][ri][w][h];
+                                        continue;
+                                    }
+                                    HmeGeom g;
+                                    if (lvl == 1)
+                                        g = push_hme_level(st, p, 1, p.ref[li][ri].lvl[1], (int16_t)st.org_x >> 1, (int16_t)st.org_y >> 1, (int)st.b64_w >> 1,
+                                                           (int)st.b64_h >> 1, (int16_t)c.hme_l1_sa.width, (int16_t)c.hme_l1_sa.height,
+                                                           st.hx[0][li][ri][w][h] >> 1, st.hy[0][li][ri][w][h] >> 1, 0, 0);
+                                    else
+                                        g = push_hme_level(st, p, 2, p.ref[li][ri].lvl[2], (int16_t)st.org_x, (int16_t)st.org_y, (int)st.b64_w, (int)st.b64_h,
+                                                           (int16_t)c.hme_l2_sa.width, (int16_t)c.hme_l2_sa.height, st.hx[1][li][ri][w][h],
+                                                           st.hy[1][li][ri][w][h], 0, 0);
+                                    st.lvl_req[li][ri][w][h] = (uint8_t)st.nreq;
+                                    st.hx[lvl][li][ri][w][h] = g.ox; st.hy[lvl][li][ri][w][h] = g.oy;
+                                }
+                        }
+                }
+                __syncthreads();
+                run_searches(sh);
+                if (tid == 0) {
+                    const int scale = (lvl == 1) ? 2 : 1;
+                    for (int li = 0; li < nl; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
+                            for (int h = 0; h < c.num_hme_sa_h; h++)
+                                for (int w = 0; w < c.num_hme_sa_w; w++) {
+                                    const int k = st.lvl_req[li][ri][w][h];
+                                    if (!k) continue;
+                                    uint32_t sad; int x, y;
+                                    key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
+                                    st.hs[lvl][li][ri][w][h] = sad;
+                                    st.hx[lvl][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[lvl][li][ri][w][h]) * scale);
+                                    st.hy[lvl][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[lvl][li][ri][w][h]) * scale);
+                                }
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- set_final_seach_centre_sb (:2182-2380), hme_prune_ref_and_adjust_sr (:2477-2518) -------------
+        if (tid == 0) {
+            {
+                int16_t cx = 0, cy = 0, sx = 0, sy = 0;
+                u64     hme_sad = 0; // survives across refs, like the reference's local
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        if (searched(p, li)) {
+                            if (c.enable_hme_flag) {
+                                int lvl = -1;
+                                if (c.enable_hme_level0_flag && !c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 0;
+                                if (c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 1;
+                                if (c.enable_hme_level2_flag) lvl = 2;
+                                if (lvl >= 0) {
+                                    cx = st.hx[lvl][li][ri][0][0]; cy = st.hy[lvl][li][ri][0][0]; hme_sad = st.hs[lvl][li][ri][0][0];
+                                    int w = 1;
+                                    for (int h = 0; h < c.num_hme_sa_h; h++) {
+                                        for (; w < c.num_hme_sa_w; w++)
+                                            if (st.hs[lvl][li][ri][w][h] < hme_sad) {
+                                                cx = st.hx[lvl][li][ri][w][h]; cy = st.hy[lvl][li][ri][w][h]; hme_sad = st.hs[lvl][li][ri][w][h];
+                                            }
+                                        w = 0;
+                                    }
+                                }
+                                sx = cx; sy = cy;
+                            }
+                        } else { sx = sy = 0; }
+                        st.hme_sc_x[li][ri] = sx; st.hme_sc_y[li][ri] = sy; st.hme_sad64[li][ri] = hme_sad;
+                    }
+            }
+            if (c.enable_hme_flag) {
+                const uint16_t th = c.prune_ref_if_hme_sad_dev_bigger_than_th;
+                if (c.enable_me_hme_ref_pruning && th != 0xFFFF) {
+                    u64 best = ~0ull;
+                    for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) best = st.hme_sad64[li][ri] < best ? st.hme_sad64[li][ri] : best;
+                    for (int li = 0; li < 2; li++) for (int ri = 1; ri < 4; ri++)
+                        if ((st.hme_sad64[li][ri] - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
+                }
+                if (c.enable_me_sr_adjustment)
+                    for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) {
+                        if (iabs(st.hme_sc_x[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th && iabs(st.hme_sc_y[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th &&
+                            st.hme_sad64[li][ri] < c.stationary_hme_sad_abs_th)
+                            st.sr_divisor[li][ri] = c.stationary_me_sr_divisor;
+                        else if (st.hme_sad64[li][ri] < c.reduce_me_sr_based_on_hme_sad_abs_th)
+                            st.sr_divisor[li][ri] = c.me_sr_divisor_for_low_hme_sad;
+                    }
+            }
+        }
+        __syncthreads();
+
+        // ---- integer_search_b64 (motion_estimation.c:1249-1516) --------------------------------------------
+        // Refs are independent except through p_sb_best_sad[0][0][0] when enable_me_sr_adjustment == 2 (and the
+        // zz early exit is off); then list0/ref0 is finished first.  Per group: (a) check_00_center SADs,
+        // (b) search-area sizing and the 1-point probe for the 8x8-variance test, (c) final window, full search.
+        {
+            const bool dep    = (!c.me_early_exit_th) && c.enable_me_sr_adjustment == 2;
+            const int  ngroup = dep ? 2 : 1;
+            for (int gi = 0; gi < ngroup; gi++) {
+                if (tid == 0) {
+                    st.nreq = 0;
+                    for (int li = 0; li < nl; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                            if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
+                            st.c00_req[li][ri] = 0;
+                            st.me_cx[li][ri] = st.hme_sc_x[li][ri]; st.me_cy[li][ri] = st.hme_sc_y[li][ri];
+                            if (c.me_early_exit_th || !st.do_ref[li][ri]) continue;
+                            int16_t cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
+                            if ((cx != 0 || cy != 0) && d.is_ref) { // check_00_center (:1139-1206)
+                                const DevPlane &rp = p.ref[li][ri].lvl[2];
+                                const int ox = (int16_t)st.org_x, oy = (int16_t)st.org_y;
+                                if (ox + cx < -63) cx = (int16_t)(-63 - ox);
+                                if (ox + cx > rp.width - 1) cx = (int16_t)(cx - ((ox + cx) - (rp.width - 1)));
+                                if (oy + cy < -63) cy = (int16_t)(-63 - oy);
+                                if (oy + cy > rp.height - 1) cy = (int16_t)(cy - ((oy + cy) - (rp.height - 1)));
+                                st.me_cx[li][ri] = cx; st.me_cy[li][ri] = cy;
+                                push_zz_req(st, rp, 0, 0);
+                                push_zz_req(st, rp, cx, cy);
+                                st.c00_req[li][ri] = (uint8_t)st.nreq; // index of the second request + 1
+                            }
+                        }
+                }
+                __syncthreads();
+                if (st.nreq) run_searches(sh); // uniform (LDS value read after the barrier)
+                if (tid == 0) {
+                    st.nme = 0; st.nprobe = 0;
+                    for (int li = 0; li < nl; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                            if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
+                            if (!st.do_ref[li][ri]) continue;
+                            const DevPlane &rp = p.ref[li][ri].lvl[2];
+                            int16_t  cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
+                            const uint32_t dist = (uint16_t)scaled_distance(ref_distance(p, li, ri));
+                            int16_t sa_w = (int16_t)imin((int)(c.me_sa.sa_min.width * dist), c.me_sa.sa_max.width);
+                            int16_t sa_h = (int16_t)imin((int)(c.me_sa.sa_min.height * dist), c.me_sa.sa_max.height);
+                            if (c.mv_sa_adj_enabled && (!c.mv_sa_adj_nearest_ref_only || ri == 0)) {
+                                if (iabs(st.hme_sc_x[li][ri]) > c.mv_sa_adj_mv_size_th) sa_w = (int16_t)(sa_w * c.mv_sa_adj_sa_multiplier);
+                                if (iabs(st.hme_sc_y[li][ri]) > c.mv_sa_adj_mv_size_th) sa_h = (int16_t)(sa_h * c.mv_sa_adj_sa_multiplier);
+                            }
+                            { const uint32_t q = (uint32_t)(int)sa_w / st.sr_divisor[li][ri]; sa_w = (int16_t)(((q > 1u ? q : 1u) + 7) & ~7u); }
+                            { const uint32_t q = (uint32_t)(int)sa_h / st.sr_divisor[li][ri]; sa_h = (int16_t)(q > 3u ? q : 3u); }
+                            const int16_t h0 = sa_h, w0 = sa_w;
+                            u64 best_hme_sad = ~0ull;
+                            if (c.me_early_exit_th) {
+                                if (st.zz_sad[li][ri] < c.me_early_exit_th / 6) sa_w = sa_h = 1;
+                            } else {
+                                int accurate = 1;
+                                const int k2 = st.c00_req[li][ri];
+                                if (k2) {
+                                    const uint32_t zero = (uint32_t)(st.req_key[k2 - 2] >> 32) << 1;
+                                    const uint32_t hme  = (uint32_t)(st.req_key[k2 - 1] >> 32) << 1;
+                                    if (zero <= hme) cx = cy = 0; // MIN(zero_cost, hme_cost) == zero_cost
+                                    best_hme_sad = hme;
+                                    if (cx == 0 && cy == 0) accurate = 0;
+                                }
+                                if (c.enable_me_sr_adjustment == 2) {
+                                    if ((accurate && best_hme_sad < 24 * 24) || (d.is_ref && st.hme_sad64[li][ri] < 24 * 24)) sa_h = (int16_t)(sa_h / 2);
+                                    if ((li || ri) && st.best_sad[0][0][0] < 5000 && sa_h == h0 && sa_w == w0) { sa_h = (int16_t)(sa_h >> 1); sa_w = (int16_t)(sa_w >> 1); }
+                                }
+                            }
+                            MeReq &m = st.me[st.nme++];
+                            m.pix0 = plane_at(rp, (int)st.org_x, (int)st.org_y); m.stride = rp.stride;
+                            m.li = (uint8_t)li; m.ri = (uint8_t)ri; m.pad = 0;
+                            m.sa_w = sa_w; m.sa_h = sa_h; // provisional size, finalised after the probe
+                            m.ox = cx; m.oy = cy;         // the search centre until then
+                            m.probe = (c.me_8x8_var_enabled && sa_w * sa_h > 24) ? 1 : 0;
+                            if (m.probe) { MeReq &pr = st.me_probe[st.nprobe++]; pr = m; pr.sa_w = pr.sa_h = 1; }
+                        }
+                }
+                __syncthreads();
+                if (st.nprobe) run_me_searches(sh, p, st.me_probe, st.nprobe); // uniform
+                if (tid == 0) {
+                    const int pic_w = (int16_t)d.aligned_width, pic_h = (int16_t)d.aligned_height;
+                    for (int i = 0; i < st.nme; i++) {
+                        MeReq &m = st.me[i];
+                        int16_t sa_w = m.sa_w, sa_h = m.sa_h;
+                        const int cx = m.ox, cy = m.oy;
+                        if (m.probe) { // :1391-1439 -- only one point was searched: 64x64 SAD == sum of the 8x8 SADs
+                            const uint32_t *b8 = &st.best_sad[m.li][m.ri][21];
+                            const uint32_t  mean = st.best_sad[m.li][m.ri][0] / 64;
+                            uint32_t ssq = 0;
+                            for (int k = 0; k < 64; k++) { const int32_t dd = (int32_t)b8[k] - (int32_t)mean; ssq += (uint32_t)(dd * dd); }
+                            const uint32_t var = ssq / 64;
+                            if (var > c.me_sr_mult2_th) { sa_w = (int16_t)((imax(1, sa_w * 3 / 2) + 7) & ~7); sa_h = (int16_t)imax(1, sa_h * 3 / 2); }
+                            if (var < c.me_sr_div4_th) { sa_w = (int16_t)((imax(1, sa_w >> 2) + 7) & ~7); sa_h = (int16_t)imax(3, imax(1, sa_h >> 2)); }
+                            else if (var < c.me_sr_div2_th) { sa_w = (int16_t)((imin(sa_w, sa_w >> 1) + 7) & ~7); sa_h = (int16_t)imax(3, imin(sa_h, sa_h >> 1)); }
+                        }
+                        int ox = (int16_t)(cx - (sa_w >> 1)), oy = (int16_t)(cy - (sa_h >> 1)), w = sa_w, h = sa_h;
+                        clip_axis((int16_t)st.org_x, ox, w, 63, pic_w);
+                        w = (w < 8) ? w : (w & ~7);
+                        clip_axis((int16_t)st.org_y, oy, h, 63, pic_h);
+                        m.ox = (int16_t)ox; m.oy = (int16_t)oy; m.sa_w = (int16_t)w; m.sa_h = (int16_t)h;
+                    }
+                }
+                __syncthreads();
+                run_me_searches(sh, p, st.me, st.nme);
+            }
+        }
+
+        // ---- me_prune_ref (motion_estimation.c:1522-1565) ----------------------------------------------------
+        if (c.enable_hme_flag && c.enable_me_hme_ref_pruning) {
+            if (tid == 0) {
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        if (!st.do_ref[li][ri]) { st.hme_sad64[li][ri] = (u64)SVT_HIP_MAX_SAD_VALUE * 64; continue; }
+                        u64 t = 0;
+                        for (int i = 0; i < 64; i++) t += st.best_sad[li][ri][21 + i];
+                        st.hme_sad64[li][ri] = t;
+                    }
+                const uint16_t th = c.prune_ref_if_me_sad_dev_bigger_than_th;
+                if (th != 0xFFFF) {
+                    u64 best = ~0ull;
+                    for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) best = st.hme_sad64[li][ri] < best ? st.hme_sad64[li][ri] : best;
+                    for (int li = 0; li < 2; li++) for (int ri = 1; ri < 4; ri++)
+                        if ((st.hme_sad64[li][ri] - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- construct_me_candidate_array* (motion_estimation.c:2532-2836), one thread per PU ----------------
+        {
+            const uint32_t n_pu = p.n_pu;
+            uint8_t  *o_total = p.res.total_me_candidate_index + (size_t)b * n_pu;
+            uint32_t *o_mv    = p.res.me_mv_array + (size_t)b * n_pu * d.max_refs;
+            uint8_t  *o_cand  = p.res.me_candidate_array + (size_t)b * n_pu * d.max_cand;
+            const int r0 = d.num_of_ref_pic_to_search[0], r1 = d.num_of_ref_pic_to_search[1];
+            const int n  = tid;
+            auto use_pu = [&](int nn) { return d.enable_me_16x16 ? (d.enable_me_8x8 || nn < 21) : nn < 5; };
+            auto pack   = [](unsigned dir, unsigned i0, unsigned i1, unsigned l0, unsigned l1) {
+                return (uint8_t)((dir & 3) | ((i0 & 3) << 2) | ((i1 & 3) << 4) | ((l0 & 1) << 6) | ((l1 & 1) << 7));
+            };
+            // the reference writes these arrays only partially (malloc'ed): start every block from zero
+            for (int i = tid; i < (int)(n_pu * d.max_refs); i += kThreads) o_mv[i] = 0;
+            for (int i = tid; i < (int)(n_pu * d.max_cand); i += kThreads) o_cand[i] = 0;
+            for (int i = tid; i < (int)n_pu; i += kThreads) o_total[i] = 0;
+            __syncthreads();
+            if (n < d.max_number_of_pus_per_sb) {
+                const int use = use_pu(n);
+                uint32_t  nls = nl;
+                if (r0 == 1 && r1 == 0) { // construct_me_candidate_array_single_ref
+                    const int pu   = c_z_to_raster[n];
+                    st.me_dist[pu] = st.best_sad[0][0][n];
+                    if (use) o_total[pu] = 1;
+                    if (st.do_ref[0][0] && use) { o_cand[pu * d.max_cand] = pack(0, 0, 0, 0, 0); o_mv[pu * d.max_refs] = st.best_mv[0][0][n]; }
+                } else if (r0 == 1 && r1 == 1) { // construct_me_candidate_array_mrp_off
+                    const int     pu = c_z_to_raster[n];
+                    const uint8_t d0 = st.do_ref[0][0], d1 = (nls == 1) ? 0 : st.do_ref[1][0];
+                    if (nls < 2 || !st.do_ref[1][0]) nls = 1;
+                    const uint32_t prune_th = (d0 && d1) ? (uint32_t)c.prune_me_candidates_th : 0;
+                    uint8_t  blk[2] = {d0, d1};
+                    uint8_t  off = 0;
+                    const uint32_t s0 = st.best_sad[0][0][n], s1 = st.best_sad[1][0][n];
+                    const uint32_t best = (d0 && d1) ? (s0 < s1 ? s0 : s1) : (d0 ? s0 : s1);
+                    st.me_dist[pu] = best;
+                    if (use) o_total[pu] = 1;
+                    int min_list = -1;
+                    if (c.use_best_unipred_cand_only && blk[0] && blk[1]) min_list = s0 < s1 ? 0 : 1;
+                    for (uint32_t li = 0; li < nls && (use || off == 0); li++) {
+                        if (!blk[li]) continue;
+                        if (prune_th > 0) {
+                            const uint32_t dev = (st.best_sad[li][0][n] - best) * 100;
+                            if (dev > best * prune_th) { blk[li] = 0; continue; }
+                        }
+                        if (min_list != -1 && min_list != (int)li) {
+                            if (use) o_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
+                            continue;
+                        }
+                        if (use) {
+                            o_cand[pu * d.max_cand + off] = pack(li, 0, 0, li == 0 ? li : 24, li == 1 ? li : 24);
+                            o_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
+                        }
+                        off++;
+                    }
+                    if (blk[0] && blk[1] && use) { o_cand[pu * d.max_cand + off] = pack(2, 0, 0, 0, 1); o_total[pu] = (uint8_t)(off + 1); }
+                } else { // construct_me_candidate_array
+                    const int pu = (n > 4) ? c_z_to_raster[n] : n;
+                    uint8_t   off = 0;
+                    uint8_t   blk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                    const uint32_t prune_th = (uint32_t)c.prune_me_candidates_th;
+                    uint32_t       best     = ~0u;
+                    for (uint32_t li = 0; li < nls; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                            blk[li][ri] = st.do_ref[li][ri];
+                            if (blk[li][ri]) best = st.best_sad[li][ri][n] < best ? st.best_sad[li][ri][n] : best;
+                        }
+                    st.me_dist[pu] = best;
+                    for (uint32_t li = 0; li < nls && (use || off == 0); li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li] && (use || off == 0); ri++) {
+                            if (!blk[li][ri]) continue;
+                            if (prune_th > 0) {
+                                const uint32_t dev = (st.best_sad[li][ri][n] - best) * 100;
+                                if (dev > best * prune_th) { blk[li][ri] = 0; continue; }
+                            }
+                            if (use) {
+                                o_cand[pu * d.max_cand + off] = pack(li, ri, ri, li == 0 ? li : 24, li == 1 ? li : 24);
+                                o_mv[pu * d.max_refs + (li ? d.max_l0 : 0) + ri] = st.best_mv[li][ri][n];
+                            }
+                            off++;
+                        }
+                    if (nls == 2 && use) {
+                        for (int a = 0; a < r0; a++)
+                            for (int bb = 0; bb < r1; bb++) {
+                                if (d.only_l_bwd && (a > 0 || bb > 0)) continue;
+                                if (blk[0][a] && blk[1][bb]) o_cand[pu * d.max_cand + off++] = pack(2, a, bb, 0, 1);
+                            }
+                        if (!d.only_l_bwd) {
+                            for (int a = 1; a < r0; a++)
+                                if (blk[0][0] && blk[0][a]) o_cand[pu * d.max_cand + off++] = pack(2, 0, a, 0, 0);
+                            if (r1 == 3 && blk[1][0] && blk[1][2]) o_cand[pu * d.max_cand + off++] = pack(2, 0, 2, 1, 1);
+                        }
+                    }
+                    if (use) o_total[pu] = off;
+                }
+            }
+            __syncthreads();
+
+            // ---- compute_distortion (:2964-3008) + perform_gm_detection (:2838-2961) ---------------------------
+            if (tid == 0) {
+                uint32_t d32 = 0, d16 = 0, d8 = 0;
+                for (int i = 0; i < 4; i++) d32 += st.me_dist[1 + i];
+                for (int i = 0; i < 16; i++) d16 += st.me_dist[5 + i];
+                for (int i = 0; i < 64; i++) d8 += st.me_dist[21 + i];
+                const u64 mean = d8 / 64;
+                u64 ssq = 0;
+                for (int i = 0; i < 64; i++) { const long long dd = (long long)st.me_dist[21 + i] - (long long)mean; ssq += (u64)(dd * dd); }
+                const uint32_t pix = st.b64_w * st.b64_h;
+                p.res.me_8x8_cost_variance[b] = (uint32_t)(ssq / 64);
+                p.res.rc_me_distortion[b]     = d.input_resolution <= 2 ? d8 : d16;
+                p.res.me_64x64_distortion[b]  = (st.me_dist[0] * 4096u) / pix;
+                p.res.me_32x32_distortion[b]  = (d32 * 4096u) / pix;
+                p.res.me_16x16_distortion[b]  = (d16 * 4096u) / pix;
+                p.res.me_8x8_distortion[b]    = (d8 * 4096u) / pix;
+                uint8_t stationary = 0, allow_gm = 0;
+                if (d.gm_enabled) {
+                    uint32_t cnt[32]; // [list][ref][component][sign]
+                    for (int i = 0; i < 32; i++) cnt[i] = 0;
+                    uint32_t tot = 0, still = 0;
+                    const int low = d.input_resolution <= 2;
+                    const int nn  = low ? 64 : 16;
+                    for (int i = 0; i < nn; i++) {
+                        int idx = (low ? 21 : 5) + i;
+                        if (low && !d.enable_me_8x8) {
+                            if (idx >= 21) idx = c_8x8_to_16x16[idx - 21];
+                            if (!d.enable_me_16x16 && idx >= 5) idx = c_16x16_to_32x32[idx - 5];
+                        } else if (!low && !d.enable_me_16x16 && idx >= 5) idx = c_16x16_to_32x32[idx - 5];
+                        const uint8_t  cb  = o_cand[idx * d.max_cand];
+                        const unsigned dir = cb & 3;
+                        const unsigned li  = (dir == 0 || dir == 2) ? ((cb >> 6) & 1) : ((cb >> 7) & 1);
+                        const unsigned ri  = (dir == 0 || dir == 2) ? ((cb >> 2) & 3) : ((cb >> 4) & 3);
+                        const u64 a = d.picture_number, bb = d.ref_picture_number[li][ri];
+                        int th;
+                        if (low) { const int dist = (uint16_t)iabs((int)(int16_t)((a > bb ? a : bb) - (a < bb ? a : bb))); th = d.gm_use_distance_based_active_th ? imax(dist >> 1, 4) : 4; }
+                        else     { const int dist = (uint16_t)iabs((int)(int16_t)(a - bb)); th = d.gm_use_distance_based_active_th ? imax(dist * 16, 32) : 32; }
+                        const uint32_t mv = st.best_mv[li][ri][idx];
+                        const int mx = (int)(int16_t)(mv & 0xFFFF) << 2, my = (int)(int16_t)(mv >> 16) << 2;
+                        const int base = (int)(li * 4 + ri) * 4;
+                        if (mx < -th) cnt[base + 0]++; else if (mx > th) cnt[base + 1]++;
+                        if (my < -th) cnt[base + 2]++; else if (my > th) cnt[base + 3]++;
+                        const int sth = low ? 0 : 4;
+                        if (iabs(mx) <= sth && iabs(my) <= sth) still++;
+                        tot++;
+                    }
+                    if (still > (tot * 5) / 100) stationary = 1;
+                    for (int i = 0; i < 32; i++) if (cnt[i] > tot / 2) allow_gm = 1;
+                }
+                p.res.stationary_block_present_sb[b] = stationary;
+                p.res.rc_me_allow_gm[b]              = allow_gm;
+            }
+            // ---- optional search-level results ------------------------------------------------------------------
+            if (p.res.sb_best_sad || p.res.sb_best_mv)
+                for (int i = tid; i < 2 * 4 * 85; i += kThreads) {
+                    const int li = i / (4 * 85), ri = (i / 85) & 3, nn = i % 85;
+                    const bool ok = li < nl && ri < d.num_of_ref_pic_to_search[li] && st.do_ref[li][ri];
+                    if (p.res.sb_best_sad) p.res.sb_best_sad[(size_t)b * 680 + i] = ok ? st.best_sad[li][ri][nn] : SVT_HIP_MAX_SAD_VALUE;
+                    if (p.res.sb_best_mv) p.res.sb_best_mv[(size_t)b * 680 + i] = ok ? st.best_mv[li][ri][nn] : 0;
+                }
+            if (tid < 8) {
+                const int li = tid >> 2, ri = tid & 3;
+                const bool live = li < nl && ri < d.num_of_ref_pic_to_search[li];
+                if (p.res.do_ref) p.res.do_ref[(size_t)b * 8 + tid] = live ? st.do_ref[li][ri] : 0;
+                if (p.res.hme_sad) p.res.hme_sad[(size_t)b * 8 + tid] = live ? (uint32_t)st.hme_sad64[li][ri] : 0;
+                if (p.res.hme_sc) {
+                    p.res.hme_sc[((size_t)b * 8 + tid) * 2]     = live ? st.hme_sc_x[li][ri] : 0;
+                    p.res.hme_sc[((size_t)b * 8 + tid) * 2 + 1] = live ? st.hme_sc_y[li][ri] : 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t svt_hip_me_kernel_lds_bytes(void) { return sizeof(Shared); }
+
+#include "svt_hip_internal.h"
+
+// Host launcher: zero the band queues, size the grid from residency (2 workgroups per CU at this kernel's
+// register/LDS footprint) and enqueue on the context stream.
+int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, uint32_t n_jobs) {
+    if (n_jobs == 0) return SVT_HIP_OK;
+    SVT_HIP_CHECK(ctx, hipMemsetAsync(ctx->queue_head, 0, SVT_HIP_ME_QUEUES * sizeof(uint32_t), ctx->stream));
+    const size_t lds = sizeof(Shared);
+    static bool  attr_set = false;
+    if (!attr_set) {
+        SVT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(svt_hip_me_b64_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    uint32_t grid = (uint32_t)ctx->num_cus * 2u;
+    if (grid > n_jobs) grid = n_jobs;
+    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, ctx->stream, *params);
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}

@@ -1,0 +1,150 @@
+// me_picture.hip -- host entry points of the batched open-loop ME (include/svt_hip_me.h): descriptor validation,
+// parameter block assembly, launch, and the synchronous host-pointer form.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "svt_hip_internal.h"
+
+namespace {
+
+struct Geometry {
+    uint32_t w64, h64, row0, nrow, n_pu, n_b64;
+};
+
+int validate(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *d, const SvtHipPaPicture *cur,
+             const SvtHipPaPicture *const refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS], const SvtHipMeResults *res, Geometry *g) {
+    if (!ctx || !cfg || !d || !cur || !refs || !res) return SVT_HIP_ERR_BAD_PARAM;
+    if (cfg->num_hme_sa_w != 2 || cfg->num_hme_sa_h != 2)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "num_hme_sa_w/h must be 2x2 (got %ux%u)", cfg->num_hme_sa_w, cfg->num_hme_sa_h);
+    if (cfg->hme_search_method > 1 || cfg->me_search_method > 1) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "search method must be 0 or 1");
+    const uint16_t lim = 2048; // keeps every int16 search-area product of the reference in range
+    if (cfg->me_sa.sa_max.width > lim || cfg->me_sa.sa_max.height > lim || cfg->hme_l0_sa.sa_max.width > lim ||
+        cfg->hme_l0_sa.sa_max.height > lim || cfg->prehme_sa_cfg[0].sa_max.height > lim || cfg->prehme_sa_cfg[1].sa_max.width > lim ||
+        cfg->hme_l1_sa.width > lim || cfg->hme_l1_sa.height > lim || cfg->hme_l2_sa.width > lim || cfg->hme_l2_sa.height > lim)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "search area larger than %u", lim);
+    if (d->num_of_list_to_search < 1 || d->num_of_list_to_search > SVT_HIP_MAX_LISTS)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "num_of_list_to_search %u", d->num_of_list_to_search);
+    const DevPlane &f = cur->pyr.lvl[2];
+    if (d->aligned_width != f.width || d->aligned_height != f.height || (f.width & 7) || (f.height & 7))
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "aligned size %ux%u does not match the picture %dx%d", d->aligned_width,
+                            d->aligned_height, f.width, f.height);
+    int r[2] = {0, 0};
+    for (int li = 0; li < d->num_of_list_to_search; li++) {
+        r[li] = d->num_of_ref_pic_to_search[li];
+        if (r[li] > SVT_HIP_MAX_REFS || (li == 0 && r[li] < 1)) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "list %d: %d references", li, r[li]);
+        for (int ri = 0; ri < r[li]; ri++) {
+            const SvtHipPaPicture *rp = refs[li][ri];
+            if (!rp) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "reference [%d][%d] is null", li, ri);
+            for (int l = 0; l < 3; l++)
+                if (rp->pyr.lvl[l].width != cur->pyr.lvl[l].width || rp->pyr.lvl[l].height != cur->pyr.lvl[l].height)
+                    return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "reference [%d][%d] level %d is %dx%d, picture is %dx%d", li, ri, l,
+                                        rp->pyr.lvl[l].width, rp->pyr.lvl[l].height, cur->pyr.lvl[l].width, cur->pyr.lvl[l].height);
+        }
+    }
+    if (d->max_number_of_pus_per_sb == 0 || d->max_number_of_pus_per_sb > SVT_HIP_SQUARE_PU_COUNT)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "max_number_of_pus_per_sb %u", d->max_number_of_pus_per_sb);
+    // capacity of MeSbResults rows as allocated by svt_aom_me_sb_results_ctor (pcs.c:91-117)
+    const int r1     = d->num_of_list_to_search == 2 ? d->num_of_ref_pic_to_search[1] : 0;
+    const int ncand  = (r[0] == 1 && r1 <= 1) ? (r1 ? 3 : 1) : r[0] + r1 + r[0] * r1 + (r[0] - 1) + (r1 == 3 ? 1 : 0);
+    if (d->max_cand < ncand || d->max_l0 < r[0] || d->max_refs < d->max_l0 + r1 || d->max_refs < 1)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "max_cand %u / max_refs %u / max_l0 %u too small for %d+%d references", d->max_cand,
+                            d->max_refs, d->max_l0, r[0], r1);
+    g->w64  = (d->aligned_width + 63u) / 64u;
+    g->h64  = (d->aligned_height + 63u) / 64u;
+    g->row0 = d->b64_row_start;
+    if (g->row0 >= g->h64) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "b64_row_start %u >= %u rows", g->row0, g->h64);
+    g->nrow = d->b64_row_count ? d->b64_row_count : g->h64 - g->row0;
+    if (g->row0 + g->nrow > g->h64) g->nrow = g->h64 - g->row0;
+    g->n_pu  = svt_hip_me_n_pu(d->enable_me_16x16, d->enable_me_8x8);
+    g->n_b64 = g->w64 * g->h64;
+    if (!res->total_me_candidate_index || !res->me_mv_array || !res->me_candidate_array || !res->me_64x64_distortion ||
+        !res->me_32x32_distortion || !res->me_16x16_distortion || !res->me_8x8_distortion || !res->rc_me_distortion ||
+        !res->me_8x8_cost_variance || !res->stationary_block_present_sb || !res->rc_me_allow_gm)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory result pointer is null");
+    return SVT_HIP_OK;
+}
+
+struct Field { size_t off, elem, count; bool optional; };
+
+// layout of one result set inside a single device allocation (used by the synchronous entry)
+size_t layout(const Geometry &g, const SvtHipMePictureDesc *d, const SvtHipMeResults *host, SvtHipMeResults *dev, uint8_t *base,
+              Field f[16]) {
+    const size_t nb = g.n_b64;
+    const size_t counts[16] = {g.n_pu, (size_t)g.n_pu * d->max_refs, (size_t)g.n_pu * d->max_cand, 1, 1, 1, 1, 1, 1, 1, 1, 680, 680, 16, 8, 8};
+    const size_t elems[16]  = {1, 4, 1, 4, 4, 4, 4, 4, 4, 1, 1, 4, 4, 2, 4, 1};
+    void *const *hp = reinterpret_cast<void *const *>(host);
+    void       **dp = reinterpret_cast<void **>(dev);
+    size_t       off = 0;
+    for (int i = 0; i < 16; i++) {
+        f[i].elem = elems[i]; f[i].count = counts[i] * nb; f[i].optional = i >= 11; f[i].off = off;
+        if (hp[i]) { dp[i] = base ? base + off : nullptr; off += (f[i].count * f[i].elem + 255) & ~(size_t)255; }
+        else dp[i] = nullptr;
+    }
+    return off;
+}
+
+} // namespace
+
+extern "C" {
+
+int svt_hip_me_picture_async(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, const SvtHipPaPicture *cur,
+                             const SvtHipPaPicture *const refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS], const SvtHipMeResults *res_dev) {
+    Geometry g;
+    int rc = validate(ctx, cfg, desc, cur, refs, res_dev, &g);
+    if (rc) return rc;
+    MeKernelParams p;
+    memset(&p, 0, sizeof(p));
+    p.cfg  = *cfg;
+    p.desc = *desc;
+    p.cur  = cur->pyr;
+    for (int li = 0; li < desc->num_of_list_to_search; li++)
+        for (int ri = 0; ri < desc->num_of_ref_pic_to_search[li]; ri++) p.ref[li][ri] = refs[li][ri]->pyr;
+    p.res  = *res_dev;
+    p.w64  = g.w64;
+    p.row0 = g.row0;
+    p.n_pu = g.n_pu;
+    // eight contiguous row bands, one queue each (neighbouring blocks share reference windows -> same XCD L2)
+    for (int q = 0; q <= SVT_HIP_ME_QUEUES; q++) p.queue_begin[q] = (uint32_t)(((uint64_t)g.nrow * q) / SVT_HIP_ME_QUEUES) * g.w64;
+    p.queue_head = ctx->queue_head;
+    hipSetDevice(ctx->device);
+    return svt_hip_me_launch(ctx, &p, g.nrow * g.w64);
+}
+
+int svt_hip_me_picture(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, const SvtHipPaPicture *cur,
+                       const SvtHipPaPicture *const refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS], SvtHipMeResults *res) {
+    Geometry g;
+    int rc = validate(ctx, cfg, desc, cur, refs, res, &g);
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    Field           f[16];
+    SvtHipMeResults dev;
+    const size_t    bytes = layout(g, desc, res, &dev, nullptr, f);
+    void           *scratch;
+    if ((rc = svt_hip_scratch(ctx, bytes, &scratch))) return rc;
+    layout(g, desc, res, &dev, static_cast<uint8_t *>(scratch), f);
+    if ((rc = svt_hip_me_picture_async(ctx, cfg, desc, cur, refs, &dev))) return rc;
+    // copy back only the rows of this call's band
+    void *const *hp = reinterpret_cast<void *const *>(res);
+    void *const *dp = reinterpret_cast<void *const *>(&dev);
+    for (int i = 0; i < 16; i++) {
+        if (!hp[i]) continue;
+        const size_t per_b64 = f[i].count / g.n_b64 * f[i].elem;
+        const size_t lo = (size_t)g.row0 * g.w64 * per_b64, n = (size_t)g.nrow * g.w64 * per_b64;
+        SVT_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t *>(hp[i]) + lo, static_cast<const uint8_t *>(dp[i]) + lo, n, hipMemcpyDeviceToHost,
+                                          ctx->stream));
+    }
+    SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SVT_HIP_OK;
+}
+
+size_t svt_hip_sizeof(int what) {
+    switch (what) {
+    case 0: return sizeof(SvtHipMeConfig);
+    case 1: return sizeof(SvtHipMePictureDesc);
+    case 2: return sizeof(SvtHipPlaneDesc);
+    case 3: return sizeof(SvtHipMeResults);
+    case 4: return sizeof(SvtHipMePresetDesc);
+    default: return 0;
+    }
+}
+
+} // extern "C"
