@@ -1,0 +1,113 @@
+"""Generates tests/golden/*.npz from the REFERENCE build (oracle/_ref/libsvtref.so).
+
+Run in the build container (needs /root/reference to have been compiled by oracle/Makefile):
+    python oracle/gen_golden.py
+Each fixture stores the inputs (frames, descriptor bytes) and the outputs of the reference's own
+svt_aom_motion_estimation_b64 / `_c` kernels, so that the GPU box -- which has no /root/reference --
+can pin both the oracle and the HIP path.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+import pyoracle  # noqa: E402
+from me_cases import MeCase  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+ME_CASES = {
+    # name: MeCase kwargs
+    "me_cif_m6_b": dict(width=352, height=288, enc_mode=6),
+    "me_cif_m12_b": dict(width=352, height=288, enc_mode=12, temporal_layer_index=3),
+    "me_cif_m8_noise": dict(width=352, height=288, enc_mode=8, kind="noise"),
+    "me_cif_m0_mrp": dict(width=352, height=288, enc_mode=0, cur=2, refs={(0, 0): 1, (0, 1): 0, (1, 0): 3, (1, 1): 4}, n_frames=5),
+    "me_cif_m6_p_base": dict(width=352, height=288, enc_mode=6, refs={(0, 0): 0}, temporal_layer_index=0),
+    "me_odd_m6_b": dict(width=360, height=296, enc_mode=6, seed=5),  # partial b64 columns/rows (40x40 edge blocks)
+    "me_cif_m4_gm": dict(width=352, height=288, enc_mode=4, gm_enabled=1, kind="fastpan"),
+    "me_cif_m10_sc": dict(width=352, height=288, enc_mode=10, sc_class1=1, kind="extremes"),
+}
+
+
+def gen_me():
+    for name, kw in ME_CASES.items():
+        c = MeCase(**kw)
+        out = c.run_cpu("ref")
+        chk = c.run_cpu("oracle")
+        for k in out:
+            assert np.array_equal(out[k], chk[k]), (name, k)
+        frames = {"cur": c.cur.inner(2)}
+        for (li, ri), p in c.refs.items():
+            frames[f"ref_{li}_{ri}"] = p.inner(2)
+        meta = dict(cfg=np.frombuffer(bytes(c.cfg), np.uint8), desc=np.frombuffer(bytes(c.desc), np.uint8))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **frames, **meta, **{"out_" + k: v for k, v in out.items()})
+        print("wrote", name, {k: v.shape for k, v in list(out.items())[:3]})
+
+
+def gen_sad_kernels():
+    """Known-answer vectors for the SAD leaf kernels, produced by the reference `_c` functions
+    (grid modelled on test/SadTest.cc:57-112,433-444: block sizes x search areas x patterns)."""
+    ref = pyoracle.load_ref()
+    rng = np.random.default_rng(2024)
+    recs = []
+    blocks = [(16, 8), (16, 16), (32, 16), (64, 32), (8, 8), (24, 12), (48, 24), (64, 64), (128, 128), (6, 4), (14, 7)]
+    areas = [(1, 1), (8, 3), (16, 9), (24, 7), (48, 48), (5, 11), (96, 1)]
+    for pattern in ("random", "ref_max", "src_max", "equal"):
+        for (bw, bh) in blocks:
+            for (sw, sh) in areas:
+                for skip in (0, 1):
+                    if skip and not (bw == 16 and bh <= 16):
+                        continue
+                    stride = bw + sw + 13
+                    rows = bh + sh + 2
+                    if pattern == "random":
+                        src = rng.integers(0, 256, (bh, bw), dtype=np.uint8)
+                        refp = rng.integers(0, 256, (rows, stride), dtype=np.uint8)
+                    elif pattern == "ref_max":
+                        src = np.zeros((bh, bw), np.uint8); refp = np.full((rows, stride), 255, np.uint8)
+                    elif pattern == "src_max":
+                        src = np.full((bh, bw), 255, np.uint8); refp = np.zeros((rows, stride), np.uint8)
+                    else:
+                        src = np.full((bh, bw), 77, np.uint8); refp = np.full((rows, stride), 77, np.uint8)
+                    src = np.ascontiguousarray(src)
+                    best = C.c_uint64(0); xs = C.c_int16(-7); ys = C.c_int16(-7)
+                    ref.svt_sad_loop_kernel_c(src.ctypes.data_as(C.c_void_p), C.c_uint32(bw), refp.ctypes.data_as(C.c_void_p), C.c_uint32(stride),
+                                              C.c_uint32(bh), C.c_uint32(bw), C.byref(best), C.byref(xs), C.byref(ys), C.c_uint32(stride),
+                                              C.c_uint8(skip), C.c_int16(sw), C.c_int16(sh))
+                    recs.append(dict(src=src, ref=refp, bw=bw, bh=bh, sw=sw, sh=sh, skip=skip, best=best.value, x=xs.value, y=ys.value))
+    np.savez_compressed(os.path.join(OUT, "sad_loop_kat.npz"),
+                        meta=np.array([[r["bw"], r["bh"], r["sw"], r["sh"], r["skip"], r["best"], r["x"], r["y"]] for r in recs], np.int64),
+                        src=np.concatenate([r["src"].ravel() for r in recs]), ref=np.concatenate([r["ref"].ravel() for r in recs]),
+                        ref_stride=np.array([r["ref"].shape[1] for r in recs], np.int64), ref_rows=np.array([r["ref"].shape[0] for r in recs], np.int64))
+    print("wrote sad_loop_kat", len(recs))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    assert pyoracle.ref_available(), "build oracle/_ref first (make -C oracle ref)"
+    gen_me()
+    gen_sad_kernels()
+
+
+def gen_presets():
+    """Every (preset, resolution class, sc, rtc, layer, levels, qp, fps) -> the reference's MeContext controls."""
+    import itertools
+    from svt_av1_psyex_amd import abi
+    keys, cfgs = [], []
+    for em, res, sc, rtc, tl, hl, qp, fr in itertools.product(range(-3, 14), range(7), (0, 1), (0, 1), (0, 2), (3, 4), (20, 35, 63), (0, 30 << 16)):
+        pd = abi.MePresetDesc(enc_mode=em, input_resolution=res, sc_class1=sc, rtc_tune=rtc, temporal_layer_index=tl, hierarchical_levels=hl,
+                              qp=qp, frame_rate_q16=fr, safe_limit_nref=tl & 1, safe_limit_zz_th=5000)
+        keys.append([em, res, sc, rtc, tl, hl, qp, fr])
+        cfgs.append(np.frombuffer(bytes(pyoracle.config_from_preset_ref(pd)), np.uint8))
+    np.savez_compressed(os.path.join(OUT, "me_presets.npz"), keys=np.array(keys, np.int64), cfg=np.stack(cfgs))
+    print("wrote me_presets", len(keys))
+
+
+if __name__ == "__main__":
+    gen_presets()

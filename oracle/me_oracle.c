@@ -9,6 +9,7 @@
  *
  * Each function cites the reference file:line (relative to Source/Lib/) whose behaviour it restates.
  */
+#include <stdbool.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -85,7 +86,7 @@ static uint32_t sad8x8_me(const uint8_t *src, uint32_t ss, const uint8_t *ref, u
 void orc_ext_sad_calculation_8x8_16x16(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
                                        uint32_t *p_best_sad_8x8, uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8,
                                        uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16, uint32_t *p_sad8x8,
-                                       int sub_sad) {
+                                       bool sub_sad) {
     uint32_t total = 0;
     for (int q = 0; q < 4; q++) {
         const uint32_t off_s = (q >> 1) * 8 * src_stride + (q & 1) * 8;
@@ -139,7 +140,7 @@ static uint32_t mv_add_x(uint32_t mv, int k) {
 void orc_ext_all_sad_calculation_8x8_16x16(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
                                            uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8,
                                            uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16,
-                                           uint32_t p_eight_sad16x16[16][8], uint32_t p_eight_sad8x8[64][8], int sub_sad) {
+                                           uint32_t p_eight_sad16x16[16][8], uint32_t p_eight_sad8x8[64][8], bool sub_sad) {
     (void)p_eight_sad8x8;
     for (int b = 0; b < 16; b++) {
         const int      z16 = k_raster16_to_z[b];

@@ -27,6 +27,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SvtHipError(f"{LIB_PATH} is missing: build it with `make -C svt-av1-psyex_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; whichever copy is loaded first serves the whole process.
+        # Load torch's first so that torch tensors / streams and this library share ONE HIP runtime.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional plumbing; the library itself only needs the ROCm runtime
+            pass
         L = C.CDLL(LIB_PATH)
         L.svt_hip_last_error.restype = C.c_char_p
         L.svt_hip_last_error.argtypes = [C.c_void_p]

@@ -201,7 +201,7 @@ __device__ void plan_tiles(St &st) {
 }
 
 // all threads: copy the tiles' reference windows into the LDS arena with aligned 16-byte loads
-__device__ void stage_tiles(Shared &sh) {
+__device__ __forceinline__ void stage_tiles(Shared &sh) {
     const St &st = sh.st;
     for (int ti = 0; ti < st.ntile; ti++) {
         const Tile &t = st.tile[ti];
@@ -266,7 +266,7 @@ __device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, cons
 __device__ __forceinline__ void lds_min_u64(u64 *addr, u64 v) { atomicMin(addr, v); }
 
 // all threads: evaluate every tile of the current plan
-__device__ void eval_tiles(Shared &sh) {
+__device__ __forceinline__ void eval_tiles(Shared &sh) {
     St &st = sh.st;
     // zero the narrow accumulators
     for (int ti = 0; ti < st.ntile; ti++) {
@@ -337,7 +337,7 @@ __device__ void eval_tiles(Shared &sh) {
 
 // all threads: run st.req[0 .. nreq) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x),
 // or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.
-__device__ void run_searches(Shared &sh) {
+__device__ __forceinline__ void run_searches(Shared &sh) {
     St &st = sh.st;
     if (threadIdx.x == 0) {
         st.next_req = 0; st.next_x = 0; st.next_y = 0;
@@ -411,7 +411,7 @@ __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
 
 // all threads: integer search for the refs in st.me[0..nme).  `merge` semantics follow the reference: strict
 // `<` against what is already in best_sad (initial MAX_SAD_VALUE, or the probe's result).
-__device__ void run_me_searches(Shared &sh, const MeKernelParams &p, const MeReq *list, int count) {
+__device__ __forceinline__ void run_me_searches(Shared &sh, const MeKernelParams &p, const MeReq *list, int count) {
     St       &st   = sh.st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub  = (p.cfg.me_search_method == 0);
@@ -433,7 +433,8 @@ __device__ void run_me_searches(Shared &sh, const MeKernelParams &p, const MeReq
         // tile the search area by rows (and columns) so that the window fits the arena
         const int W = m.sa_w, H = m.sa_h;
         int       tw = W, th = H;
-        auto wbytes = [&](int ww, int hh) { return (uint32_t)(((15 + ww - 1 + 64 + 15) & ~15) + 8) * (uint32_t)(hh - 1 + 64); };
+        auto me_pitch = [](int shift, int ww) { return ((shift + ww - 1 + 64 + 15) & ~15) + 16; };
+        auto wbytes = [&](int ww, int hh) { return (uint32_t)me_pitch(15, ww) * (uint32_t)(hh - 1 + 64); };
         while (th > 1 && wbytes(tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
         while (tw > 8 && wbytes(tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
         for (int y0 = 0; y0 < H; y0 += th)
@@ -441,11 +442,7 @@ __device__ void run_me_searches(Shared &sh, const MeKernelParams &p, const MeReq
                 const int w = imin(tw, W - x0), h = imin(th, H - y0);
                 const uint8_t *gwin  = m.pix0 + (m.ox + x0) + (long long)(m.oy + y0) * m.stride;
                 const int      shift = (int)((uintptr_t)gwin & 15);
-                // pitch: multiple of 16 bytes and == 8 (mod 32) dwords-wise -> the 8 block rows of a lane column
-                // land on distinct bank groups for the 8-byte reads
-                int pitch = (shift + w - 1 + 64 + 15) & ~15;
-                if (((pitch >> 2) & 7) != 2) pitch += ((2 - ((pitch >> 2) & 7)) & 7) << 2;
-                pitch     = (pitch + 15) & ~15; // keep 16-byte rows (pitch/4 mod 8 == 2 is not reachable with 16B rows: settle for +8 dwords)
+                const int pitch = me_pitch(shift, w); // 16-byte rows; same formula as the tile sizing above
                 const int rows        = h - 1 + 64;
                 const int vec_per_row = pitch >> 4;
                 __syncthreads(); // previous tile fully consumed

@@ -1,0 +1,46 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares; struct layouts agree."""
+import ctypes as C
+import glob
+import os
+import re
+
+from svt_av1_psyex_amd import abi, api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    syms = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\b(svt_hip_\w+)\s*\(", text):
+            # static inline helpers are not exported
+            line_start = text.rfind("\n", 0, m.start())
+            if "static inline" in text[line_start:m.start()]:
+                continue
+            syms.add(m.group(1))
+    return sorted(syms)
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.lib()
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    assert not missing, f"declared in include/*.h but not exported by libsvthip.so: {missing}"
+    assert len(declared_symbols()) >= 15
+
+
+def test_struct_sizes_match_compiled_layout(oracle):
+    L = api.lib()
+    for i, t in enumerate([abi.MeConfig, abi.MePictureDesc, abi.PlaneDesc, abi.MeResults, abi.MePresetDesc]):
+        assert C.sizeof(t) == L.svt_hip_sizeof(i) == oracle.orc_sizeof(i), t.__name__
+
+
+def test_bad_descriptor_is_rejected_without_a_gpu():
+    L = api.lib()
+    cfg = abi.MeConfig()
+    assert L.svt_hip_me_config_from_preset(None, C.byref(cfg)) == 2
+    pd = abi.MePresetDesc(enc_mode=99)
+    assert L.svt_hip_me_config_from_preset(C.byref(pd), C.byref(cfg)) == 2
+    assert L.svt_hip_input_resolution(3840, 2160) == 5 and L.svt_hip_input_resolution(1920, 1080) == 4
+    assert L.svt_hip_input_resolution(352, 288) == 0

@@ -1,0 +1,142 @@
+"""GPU: the HIP open-loop ME (libsvthip.so, through the C-ABI) against the golden fixtures and the oracle."""
+import numpy as np
+import pytest
+
+from golden_io import GoldenMeCase, me_fixture_names
+from me_cases import MeCase, compare
+from test_oracle_vs_ref import ME_GRID
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", me_fixture_names())
+def test_hip_matches_reference_fixture(hip_ctx, name):
+    case = GoldenMeCase(name)
+    assert not compare(case.expected, case.run_hip(hip_ctx)), name
+
+
+@pytest.mark.parametrize("kw", ME_GRID, ids=lambda k: f"{k['width']}x{k['height']}_m{k['enc_mode']}_{k.get('kind', 'pan')}")
+def test_hip_matches_oracle(hip_ctx, kw):
+    case = MeCase(**kw)
+    assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
+
+
+def test_full_sad_search_method(hip_ctx):
+    def full(cfg):
+        cfg.hme_search_method = 1
+        cfg.me_search_method = 1
+    case = MeCase(352, 288, enc_mode=6, cfg_edit=full)
+    assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
+
+
+def test_large_search_areas_are_tiled(hip_ctx):
+    """MR-class search areas do not fit the LDS arena in one piece: exercises the tile planner."""
+    def big(cfg):
+        cfg.me_sa.sa_min.width = cfg.me_sa.sa_min.height = 96
+        cfg.me_sa.sa_max.width = cfg.me_sa.sa_max.height = 192
+        cfg.hme_l0_sa.sa_min.width = cfg.hme_l0_sa.sa_min.height = 240
+        cfg.hme_l0_sa.sa_max.width = cfg.hme_l0_sa.sa_max.height = 480
+        cfg.me_early_exit_th = 0
+        cfg.me_8x8_var_enabled = 0
+    case = MeCase(640, 360, enc_mode=0, cfg_edit=big, kind="noise", seed=3)
+    assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
+
+
+def test_device_pyramid_equals_host_pyramid(hip_ctx):
+    case = MeCase(360, 296, enc_mode=6, seed=5)
+    pic = hip_ctx.upload(case.cur, device_pyramid=True)
+    try:
+        for level in (0, 1, 2):
+            buf, stride, p, w, h = case.cur.planes[level]
+            assert np.array_equal(pic.download(level), buf[:, :w + 2 * p]), level
+    finally:
+        pic.free()
+    assert not compare(case.run_hip(hip_ctx, device_pyramid=False), case.run_hip(hip_ctx, device_pyramid=True))
+
+
+def test_row_bands_equal_whole_picture(hip_ctx):
+    """The multi-GPU partition: any split into b64 row bands reproduces the whole-picture results."""
+    case = MeCase(640, 360, enc_mode=6, seed=9)
+    whole = case.run_hip(hip_ctx)
+    cur = hip_ctx.upload(case.cur)
+    refs = {k: hip_ctx.upload(v) for k, v in case.refs.items()}
+    try:
+        merged = None
+        for start, count in ((0, 2), (2, 1), (3, 3)):
+            case.desc.b64_row_start, case.desc.b64_row_count = start, count
+            part = hip_ctx.me_picture(case.cfg, case.desc, cur, refs)
+            w64 = 10
+            if merged is None:
+                merged = {k: np.zeros_like(v) for k, v in part.items()}
+            for k, v in part.items():
+                merged[k][start * w64:(start + count) * w64] = v[start * w64:(start + count) * w64]
+        assert not compare(whole, merged)
+    finally:
+        case.desc.b64_row_start = case.desc.b64_row_count = 0
+        cur.free()
+        for r in refs.values():
+            r.free()
+
+
+def test_invalid_descriptors_fail_loudly(hip_ctx):
+    from svt_av1_psyex_amd import api
+    case = MeCase(352, 288, enc_mode=6)
+    cur = hip_ctx.upload(case.cur)
+    try:
+        with pytest.raises(api.SvtHipError):  # reference [1][0] missing
+            hip_ctx.me_picture(case.cfg, case.desc, cur, {(0, 0): cur})
+        case.cfg.num_hme_sa_w = 3
+        with pytest.raises(api.SvtHipError):
+            hip_ctx.me_picture(case.cfg, case.desc, cur, {(0, 0): cur, (1, 0): cur})
+    finally:
+        cur.free()
+
+
+@pytest.mark.parametrize("size,dist", [((1920, 1080), 2), ((3840, 2160), 1), ((3840, 2160), 8)])
+def test_full_size_pictures_match_oracle(hip_ctx, size, dist):
+    """BASELINE configs 1-3 at full size: the oracle finishes a 2160p picture in about a second."""
+    layer = {1: 4, 2: 3, 4: 2, 8: 1}[dist]
+    case = MeCase(size[0], size[1], enc_mode=6, cur=8, refs={(0, 0): 8 - dist, (1, 0): 8 + dist}, n_frames=17, seed=11, temporal_layer_index=layer)
+    got = case.run_hip(hip_ctx)
+    assert not compare(case.run_cpu("oracle"), got)
+    # domain property: the sequence pans by (5,3) px per frame, so the dominant list-0 64x64 MV is (5,3)*dist
+    mv = got["sb_best_mv"].reshape(-1, 2, 4, 85)[:, 0, 0, 0]
+    x, y = (mv & 0xFFFF).astype(np.int16), (mv >> 16).astype(np.int16)
+    assert np.median(x) == 5 * dist and np.median(y) == 3 * dist
+
+
+def _fuzz_cfg(rng):
+    def edit(cfg):
+        cfg.me_sa.sa_min.width = int(rng.choice([8, 16, 24, 40, 104]))
+        cfg.me_sa.sa_min.height = int(rng.choice([3, 8, 16, 37, 104]))
+        cfg.me_sa.sa_max.width = max(cfg.me_sa.sa_min.width, int(rng.choice([8, 32, 64, 136])))
+        cfg.me_sa.sa_max.height = max(cfg.me_sa.sa_min.height, int(rng.choice([3, 16, 32, 120])))
+        cfg.hme_l0_sa.sa_min.width = int(rng.choice([8, 16, 32, 64]))
+        cfg.hme_l0_sa.sa_min.height = int(rng.choice([8, 16, 32, 64]))
+        cfg.hme_l0_sa.sa_max.width = int(rng.choice([96, 192, 320]))
+        cfg.hme_l0_sa.sa_max.height = int(rng.choice([96, 192, 320]))
+        cfg.hme_l1_sa.width, cfg.hme_l1_sa.height = int(rng.choice([8, 16])), int(rng.choice([3, 5, 16]))
+        cfg.hme_l2_sa.width, cfg.hme_l2_sa.height = int(rng.choice([8, 16])), int(rng.choice([3, 7, 16]))
+        cfg.me_early_exit_th = int(rng.choice([0, 64 * 64, 64 * 64 * 8]))
+        cfg.me_8x8_var_enabled = int(rng.integers(0, 2))
+        cfg.hme_search_method = int(rng.integers(0, 2))
+        cfg.me_search_method = int(rng.integers(0, 2))
+        cfg.prehme_enable = int(rng.integers(0, 2)) if cfg.prehme_sa_cfg[0].sa_max.width else 0
+        cfg.prehme_skip_search_line = int(rng.integers(0, 2))
+        cfg.enable_me_sr_adjustment = int(rng.choice([0, 1, 2]))
+        cfg.enable_hme_level2_flag = int(rng.integers(0, 2))
+        cfg.prune_me_candidates_th = int(rng.choice([0, 30, 65]))
+    return edit
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzzed_search_controls_match_oracle(hip_ctx, seed):
+    """Random search-control combinations (areas, methods, early exits, tiling) on random content."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["pan", "noise", "fastpan", "pan"][seed % 4]
+    refs = [{(0, 0): 0, (1, 0): 4}, {(0, 0): 1, (0, 1): 0, (1, 0): 3}, {(0, 0): 0}, {(0, 0): 1, (1, 0): 3, (1, 1): 4}][seed % 4]
+    size = [(352, 288), (640, 360), (360, 296), (704, 576)][(seed // 4) % 4]
+    case = MeCase(size[0], size[1], enc_mode=int(rng.choice([2, 6, 9])), cur=2, refs=refs, n_frames=5, seed=seed, kind=kind,
+                  temporal_layer_index=int(rng.integers(0, 3)) if (1, 0) not in refs else 1 + int(rng.integers(0, 3)),
+                  cfg_edit=_fuzz_cfg(rng), gm_enabled=seed % 2)
+    assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
