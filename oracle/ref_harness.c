@@ -22,6 +22,10 @@
 #include "compute_sad_c.h"
 #include "me_sad_calculation.h"
 #include "enc_mode_config.h"
+#include "coefficients.h"
+#include "inv_transforms.h"
+#include "transforms.h"
+#include "full_loop.h"
 
 #include "../include/svt_hip_me.h"
 
@@ -319,3 +323,15 @@ int ref_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
 }
 
 size_t ref_sizeof_me_context(void) { return sizeof(MeContext); }
+
+/* ---- accessors for static / header-only data of the reference ---- */
+/* av1_scan_orders[tx_size][tx_type] (Codec/coefficients.h:2197): copies scan / iscan, returns the length */
+int ref_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
+    const int w = tx_size_wide[tx_size] > 32 ? 32 : tx_size_wide[tx_size], h = tx_size_high[tx_size] > 32 ? 32 : tx_size_high[tx_size];
+    const ScanOrder *so = &av1_scan_orders[tx_size][tx_type];
+    memcpy(scan, so->scan, sizeof(int16_t) * w * h);
+    memcpy(iscan, so->iscan, sizeof(int16_t) * w * h);
+    return w * h;
+}
+const int32_t *ref_cospi(int bit) { return cospi_arr(bit); }
+const int32_t *ref_sinpi(int bit) { return sinpi_arr(bit); }

@@ -1,0 +1,199 @@
+"""CPU, build container only: oracle/dsp_oracle.c and oracle/txfm_oracle.c against the reference's `_c` functions.
+Grids follow the reference's tests (test/ResidualTest.cc, SpatialFullDistortionTest.cc, BlockErrorTest.cc, SatdTest.cc,
+hadamard_test.cc, VarianceTest.cc, quantize_func_test.cc / QuantAsmTest.cc, FwdTxfm2dAsmTest.cc, InvTxfm2dAsmTest.cc)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from txfm_cases import TX_H, TX_W, ref_fwd, ref_inv, residual_block, valid_types
+
+P = C.c_void_p
+
+
+def p(a):
+    return a.ctypes.data_as(P)
+
+
+SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (16, 64), (64, 16), (32, 8), (128, 128)]
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_residual_and_spatial_sse(ref, oracle, bd):
+    rng = np.random.default_rng(bd)
+    dt, fr, fo = (np.uint8, "svt_residual_kernel8bit_c", "orc_residual8") if bd == 8 else (np.uint16, "svt_residual_kernel16bit_c", "orc_residual16")
+    sse_r, sse_o = ("svt_spatial_full_distortion_kernel_c", "orc_spatial_sse8") if bd == 8 else ("svt_full_distortion_kernel16_bits_c", "orc_spatial_sse16")
+    getattr(ref, sse_r).restype = C.c_uint64
+    getattr(oracle, sse_o).restype = C.c_uint64
+    for (w, h) in SIZES:
+        for pat in ("random", "max", "min"):
+            s1, s2 = w + 3, w + 8
+            a = rng.integers(0, 1 << bd, (h, s1)).astype(dt)
+            b = rng.integers(0, 1 << bd, (h, s2)).astype(dt)
+            if pat == "max":
+                a[:] = (1 << bd) - 1; b[:] = 0
+            if pat == "min":
+                a[:] = 0; b[:] = (1 << bd) - 1
+            ra, rb = np.zeros((h, w + 1), np.int16), np.zeros((h, w + 1), np.int16)
+            getattr(ref, fr)(p(a), C.c_uint32(s1), p(b), C.c_uint32(s2), p(ra), C.c_uint32(w + 1), C.c_uint32(w), C.c_uint32(h))
+            getattr(oracle, fo)(p(a), C.c_uint32(s1), p(b), C.c_uint32(s2), p(rb), C.c_uint32(w + 1), C.c_uint32(w), C.c_uint32(h))
+            assert np.array_equal(ra, rb)
+            x = getattr(ref, sse_r)(p(a), C.c_uint32(1), C.c_uint32(s1), p(b), C.c_int32(2), C.c_uint32(s2), C.c_uint32(w - 2), C.c_uint32(h))
+            y = getattr(oracle, sse_o)(p(a), C.c_uint32(1), C.c_uint32(s1), p(b), C.c_int32(2), C.c_uint32(s2), C.c_uint32(w - 2), C.c_uint32(h))
+            assert x == y
+
+
+def test_coeff_distortion_block_error_satd(ref, oracle):
+    rng = np.random.default_rng(3)
+    ref.svt_av1_block_error_c.restype = C.c_int64
+    oracle.orc_block_error.restype = C.c_int64
+    for (w, h) in SIZES[:10]:
+        for scale in (100, 1 << 15, 1 << 20):
+            c = rng.integers(-scale, scale, (h, w + 2)).astype(np.int32)
+            r = rng.integers(-scale, scale, (h, w + 5)).astype(np.int32)
+            oa, ob = np.zeros(2, np.uint64), np.zeros(2, np.uint64)
+            ref.svt_full_distortion_kernel32_bits_c(p(c), C.c_uint32(w + 2), p(r), C.c_uint32(w + 5), p(oa), C.c_uint32(w), C.c_uint32(h))
+            oracle.orc_full_distortion32(p(c), C.c_uint32(w + 2), p(r), C.c_uint32(w + 5), p(ob), C.c_uint32(w), C.c_uint32(h))
+            assert np.array_equal(oa, ob)
+            ref.svt_full_distortion_kernel_cbf_zero32_bits_c(p(c), C.c_uint32(w + 2), p(oa), C.c_uint32(w), C.c_uint32(h))
+            oracle.orc_full_distortion32_cbf_zero(p(c), C.c_uint32(w + 2), p(ob), C.c_uint32(w), C.c_uint32(h))
+            assert np.array_equal(oa, ob)
+            if scale <= 1 << 15:
+                flat_c, flat_r = np.ascontiguousarray(c[:, :w]).ravel(), np.ascontiguousarray(r[:, :w]).ravel()
+                sa, sb = C.c_int64(), C.c_int64()
+                ea = ref.svt_av1_block_error_c(p(flat_c), p(flat_r), C.c_ssize_t(w * h), C.byref(sa))
+                eb = oracle.orc_block_error(p(flat_c), p(flat_r), C.c_ssize_t(w * h), C.byref(sb))
+                assert (ea, sa.value) == (eb, sb.value)
+                assert ref.svt_aom_satd_c(p(flat_c), w * h) == oracle.orc_satd(p(flat_c), w * h)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_hadamard(ref, oracle, n):
+    rng = np.random.default_rng(n)
+    for pat in ("random", "max", "min", "alt"):
+        src = rng.integers(-255, 256, (n, n + 3)).astype(np.int16)
+        if pat == "max": src[:] = 255
+        if pat == "min": src[:] = -255
+        if pat == "alt": src[:, ::2] = 255; src[:, 1::2] = -255
+        a, b = np.zeros(n * n, np.int32), np.zeros(n * n, np.int32)
+        getattr(ref, f"svt_aom_hadamard_{n}x{n}_c")(p(src), C.c_ssize_t(n + 3), p(a))
+        getattr(oracle, f"orc_hadamard_{n}x{n}")(p(src), C.c_ssize_t(n + 3), p(b))
+        assert np.array_equal(a, b)  # same coefficient order as the reference's C code, not only the same multiset
+
+
+def test_variance(ref, oracle):
+    rng = np.random.default_rng(5)
+    for (w, h) in [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (4, 8), (8, 4), (16, 64), (64, 16), (128, 64)]:
+        for pat in ("random", "extreme"):
+            a = rng.integers(0, 256, (h, w + 1)).astype(np.uint8); b = rng.integers(0, 256, (h, w + 2)).astype(np.uint8)
+            if pat == "extreme":
+                a[:] = 255; b[:] = 0; b[h // 2:] = 3
+            s1, s2 = C.c_uint32(), C.c_uint32()
+            va = getattr(ref, f"svt_aom_variance{w}x{h}_c")(p(a), w + 1, p(b), w + 2, C.byref(s1))
+            vb = oracle.orc_variance8(p(a), w + 1, p(b), w + 2, w, h, C.byref(s2))
+            assert (va & 0xFFFFFFFF, s1.value) == (vb & 0xFFFFFFFF, s2.value), (w, h, pat)
+            a16 = rng.integers(0, 1024, (h, w + 1)).astype(np.uint16); b16 = rng.integers(0, 1024, (h, w + 2)).astype(np.uint16)
+            va = ref.svt_aom_variance_highbd_c(p(a16), w + 1, p(b16), w + 2, w, h, C.byref(s1))
+            vb = oracle.orc_variance16(p(a16), w + 1, p(b16), w + 2, w, h, C.byref(s2))
+            assert (va & 0xFFFFFFFF, s1.value) == (vb & 0xFFFFFFFF, s2.value), (w, h, pat)
+
+
+def _qtables(rng, q):
+    """zbin/round/quant/quant_shift/dequant pairs of plausible magnitude for quantizer index-like value q."""
+    deq = np.array([4 + q, 4 + q + q // 3], np.int16)
+    quant = np.array([(1 << 16) // max(int(d), 1) - 1 if d > 2 else 32767 for d in deq], np.int16)
+    return dict(zbin=(deq * 84 // 128).astype(np.int16), round=(deq * 48 // 128).astype(np.int16), quant=quant,
+                quant_shift=np.array([1 << int(rng.integers(10, 15)), 1 << int(rng.integers(10, 15))], np.int16), dequant=deq)
+
+
+@pytest.mark.parametrize("highbd", [0, 1])
+@pytest.mark.parametrize("use_qm", [0, 1])
+def test_quantizers(ref, oracle, highbd, use_qm):
+    rng = np.random.default_rng(17 + highbd + 2 * use_qm)
+    for ts in (0, 1, 2, 3, 4, 5, 8, 9, 17):
+        w, h = min(TX_W[ts], 32), min(TX_H[ts], 32)
+        n = w * h
+        log_scale = 0 if TX_W[ts] * TX_H[ts] <= 256 else (1 if TX_W[ts] * TX_H[ts] <= 1024 else 2)
+        scan, iscan = np.zeros(n, np.int16), np.zeros(n, np.int16)
+        ref.ref_scan_order(ts, 0, p(scan), p(iscan))
+        for q in (0, 7, 60, 255, 1300):
+            for pat in ("random", "zero", "dc", "minmax", "small"):
+                t = _qtables(rng, q)
+                lim = (1 << (15 if not highbd else 20)) - 1
+                co = rng.integers(-lim, lim + 1, n).astype(np.int32)
+                if pat == "zero": co[:] = 0
+                if pat == "dc": co[:] = 0; co[0] = int(rng.integers(-lim, lim))
+                if pat == "minmax": co[:] = np.where(rng.integers(0, 2, n) == 0, -lim, lim)
+                if pat == "small": co = rng.integers(-2 * q - 8, 2 * q + 9, n).astype(np.int32)
+                qm = rng.integers(16, 64, n).astype(np.uint8) if use_qm else None
+                iqm = rng.integers(16, 64, n).astype(np.uint8) if use_qm else None
+                pq, pi = (p(qm), p(iqm)) if use_qm else (None, None)
+                res = []
+                for which in ("ref", "orc"):
+                    qa, da, ea = np.full(n, 7, np.int32), np.full(n, 7, np.int32), C.c_uint16(999)
+                    if which == "ref":
+                        fn = ref.svt_aom_highbd_quantize_b_c if highbd else ref.svt_aom_quantize_b_c_ii
+                        fn(p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round"]), p(t["quant"]), p(t["quant_shift"]), p(qa), p(da), p(t["dequant"]),
+                           C.byref(ea), p(scan), p(iscan), pq, pi, C.c_int32(log_scale))
+                    else:
+                        oracle.orc_quantize_b(p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round"]), p(t["quant"]), p(t["quant_shift"]), p(qa), p(da),
+                                              p(t["dequant"]), C.byref(ea), p(scan), pq, pi, C.c_int(log_scale), C.c_int(highbd))
+                    res.append((qa, da, ea.value))
+                assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], ("b", ts, q, pat)
+                res = []
+                for which in ("ref", "orc"):
+                    qa, da, ea = np.full(n, 7, np.int32), np.full(n, 7, np.int32), C.c_uint16(999)
+                    if which == "ref":
+                        if use_qm:
+                            fn = ref.svt_av1_highbd_quantize_fp_qm_c if highbd else ref.svt_av1_quantize_fp_qm_c
+                            fn(p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round"]), p(t["quant"]), p(t["quant_shift"]), p(qa), p(da), p(t["dequant"]),
+                               C.byref(ea), p(scan), p(iscan), pq, pi, C.c_int16(log_scale))
+                        elif highbd:
+                            ref.svt_av1_highbd_quantize_fp_c(p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round"]), p(t["quant"]), p(t["quant_shift"]), p(qa),
+                                                             p(da), p(t["dequant"]), C.byref(ea), p(scan), p(iscan), C.c_int16(log_scale))
+                        else:
+                            fn = [ref.svt_av1_quantize_fp_c, ref.svt_av1_quantize_fp_32x32_c, ref.svt_av1_quantize_fp_64x64_c][log_scale]
+                            fn(p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round"]), p(t["quant"]), p(t["quant_shift"]), p(qa), p(da), p(t["dequant"]),
+                               C.byref(ea), p(scan), p(iscan))
+                    else:
+                        oracle.orc_quantize_fp(p(co), C.c_ssize_t(n), p(t["round"]), p(t["quant"]), p(qa), p(da), p(t["dequant"]), C.byref(ea), p(scan),
+                                               pq, pi, C.c_int(log_scale), C.c_int(highbd))
+                    res.append((qa, da, ea.value))
+                assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], ("fp", ts, q, pat)
+
+
+def test_cos_tables_and_scan_orders(ref, oracle):
+    ref.ref_cospi.restype = C.POINTER(C.c_int32)
+    oracle.orc_cospi.restype = C.POINTER(C.c_int32)
+    for bit in range(10, 17):
+        assert np.array_equal(np.ctypeslib.as_array(ref.ref_cospi(bit), (64,)), np.ctypeslib.as_array(oracle.orc_cospi(bit), (64,)))
+    for ts in range(19):
+        for tt in range(16):
+            a, ai, b, bi = (np.zeros(1024, np.int16) for _ in range(4))
+            n = ref.ref_scan_order(ts, tt, p(a), p(ai))
+            assert n == oracle.orc_scan_order(ts, tt, p(b), p(bi))
+            assert np.array_equal(a[:n], b[:n]) and np.array_equal(ai[:n], bi[:n]), (ts, tt)
+
+
+@pytest.mark.parametrize("ts", range(19))
+def test_fwd_and_inv_txfm2d(ref, oracle, ts):
+    rng = np.random.default_rng(100 + ts)
+    w, h = TX_W[ts], TX_H[ts]
+    wp, hp = min(w, 32), min(h, 32)
+    for tt in valid_types(ts):
+        for bd, pat in [(8, "random"), (10, "random"), (10, "max"), (10, "min"), (10, "checker"), (8, "laplace")]:
+            stride = w + int(rng.integers(0, 5))
+            r = residual_block(rng, w, h, stride, bd, pat)
+            a = ref_fwd(ref, ts, tt, r, stride, bd)
+            b = np.zeros(w * h, np.int32)
+            oracle.orc_fwd_txfm2d(p(r), p(b), C.c_uint32(stride), tt, ts)
+            assert np.array_equal(a, b), ("fwd", tt, bd, pat)
+            co = a.reshape(h, w)[:hp, :wp].copy().ravel()
+            if pat == "random":
+                co = rng.integers(-(1 << (bd + 7)), 1 << (bd + 7), wp * hp).astype(np.int32)
+            co = np.ascontiguousarray(co)
+            pred = rng.integers(0, 1 << bd, (h, stride)).astype(np.uint16)
+            ra = ref_inv(ref, ts, tt, co, pred, stride, bd)
+            rb = pred.copy()
+            oracle.orc_inv_txfm2d_add(p(co), p(pred), C.c_int32(stride), p(rb), C.c_int32(stride), tt, ts, bd)
+            assert np.array_equal(ra, rb), ("inv", tt, bd, pat)
