@@ -1,0 +1,79 @@
+/*
+ * svt_hip_dsp.h -- C-ABI of the MI355X mode-decision RD kernels (residual, forward / inverse integer AV1
+ * transforms, quantize + dequantize, coefficient-domain and pixel-domain distortion, SATD).
+ *
+ * The batched entry svt_hip_rd_batch evaluates, for every job, one iteration of the reference's tx_type_search
+ * loop body (Source/Lib/Codec/product_coding_loop.c:4764-4934):
+ *     svt_residual_kernel8bit/16bit  (Codec/pic_operators.c:101-148)
+ *  -> svt_aom_estimate_transform / svt_av1_fwd_txfm2d_{WxH} (+ svt_handle_transform{64..}) (Codec/transforms.c:2259-2631,3158)
+ *  -> svt_aom_satd                                          (Codec/common_dsp_rtcd.c:70-77)
+ *  -> svt_aom_quantize_b / svt_aom_highbd_quantize_b / svt_av1_quantize_fp / svt_av1_highbd_quantize_fp
+ *                                                           (Codec/full_loop.c:29-198,282-474)
+ *  -> svt_full_distortion_kernel32_bits                     (Codec/pic_operators.c:150-172)
+ *  -> svt_av1_inv_txfm2d_add_{WxH}                          (Codec/inv_transforms.c:2459-2716)
+ *  -> svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (picture_operators_c.c:65-83, pic_operators.c:174-197)
+ * Decision logic (which tx_type wins, rate estimation, RDOQ) stays on the host.
+ */
+#ifndef SVT_HIP_DSP_H
+#define SVT_HIP_DSP_H
+
+#include <stdint.h>
+#include "svt_hip_me.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* TxSize / TxType use the reference's enum values (Codec/definitions.h): TX_4X4=0 ... TX_64X16=18; DCT_DCT=0 ... H_FLIPADST=15 */
+#define SVT_HIP_TX_SIZES_ALL 19
+#define SVT_HIP_TX_TYPES 16
+
+/* Per-qindex quantizer rows as MacroblockPlane / Dequants hold them (Codec/full_loop.c:1627-1685): [0] = DC, [1] = AC */
+typedef struct SvtHipQuantRow {
+    int16_t zbin[2], round[2], quant[2], quant_shift[2]; /* "b" quantizer */
+    int16_t round_fp[2], quant_fp[2];                    /* "fp" quantizer */
+    int16_t dequant[2];
+} SvtHipQuantRow;
+
+typedef struct SvtHipTxJob {
+    uint32_t src_offset;  /* sample offset of the block's top-left sample in the source plane   */
+    uint32_t pred_offset; /* sample offset in the prediction plane (and in the recon plane)       */
+    uint8_t  tx_type;
+    uint8_t  quant_row;   /* index into SvtHipRdBatchDesc.quant_rows */
+    uint8_t  reserved[2];
+} SvtHipTxJob;
+
+typedef struct SvtHipRdBatchDesc {
+    uint8_t  bit_depth;     /* 8: planes are uint8; 10: planes are uint16 */
+    uint8_t  quant_kind;    /* 0 = "b" (zbin / quant_shift), 1 = "fp" */
+    uint8_t  tx_size;       /* TxSize shared by every job of this call (one kernel instantiation per size) */
+    uint8_t  reserved;
+    uint32_t n_jobs;
+    uint32_t src_stride, pred_stride; /* in samples */
+    const void           *src, *pred; /* device pointers */
+    void                 *recon;      /* device pointer or NULL; same geometry as pred */
+    const SvtHipTxJob    *jobs;       /* device pointer, n_jobs entries */
+    const SvtHipQuantRow *quant_rows; /* device pointer */
+    uint32_t              n_quant_rows;
+    /* per-job outputs (device pointers; eob .. sse mandatory) */
+    uint16_t *eob;                    /* [n_jobs] */
+    uint32_t *satd;                   /* [n_jobs] svt_aom_satd of the kept coefficients */
+    uint64_t *dist_coeff;             /* [n_jobs][2] {sum (coeff - dqcoeff)^2, sum coeff^2} */
+    uint64_t *three_quad_energy;      /* [n_jobs] energy of the frequencies a 64-point size discards (0 otherwise) */
+    uint64_t *sse;                    /* [n_jobs] sum (src - recon)^2 */
+    int32_t  *coeff, *qcoeff, *dqcoeff; /* optional: [n_jobs][min(W,32)*min(H,32)] packed like the reference */
+} SvtHipRdBatchDesc;
+
+/* Enqueues one batch on the context stream (asynchronous).  Every pointer in `d` is a DEVICE pointer.
+ * Returns non-zero (and leaves nothing enqueued) when the descriptor fails validation. */
+int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d);
+
+/* Scan order of (tx_size, tx_type) as av1_scan_orders holds it (Codec/coefficients.h:2197); returns the length. */
+int svt_hip_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan);
+int svt_hip_tx_size_wide(int tx_size);
+int svt_hip_tx_size_high(int tx_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_DSP_H */

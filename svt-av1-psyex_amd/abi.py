@@ -110,3 +110,30 @@ RESULT_FIELDS = [
 
 def n_pu(enable_me_16x16, enable_me_8x8):
     return (85 if enable_me_8x8 else 21) if enable_me_16x16 else 5
+
+
+# ---- include/svt_hip_dsp.h ------------------------------------------------------------------------------
+class QuantRow(C.Structure):
+    _fields_ = [("zbin", C.c_int16 * 2), ("round", C.c_int16 * 2), ("quant", C.c_int16 * 2), ("quant_shift", C.c_int16 * 2),
+                ("round_fp", C.c_int16 * 2), ("quant_fp", C.c_int16 * 2), ("dequant", C.c_int16 * 2)]
+
+
+class TxJob(C.Structure):
+    _fields_ = [("src_offset", C.c_uint32), ("pred_offset", C.c_uint32), ("tx_type", C.c_uint8), ("quant_row", C.c_uint8),
+                ("reserved", C.c_uint8 * 2)]
+
+
+class RdBatchDesc(C.Structure):
+    _fields_ = [("bit_depth", C.c_uint8), ("quant_kind", C.c_uint8), ("tx_size", C.c_uint8), ("reserved", C.c_uint8),
+                ("n_jobs", C.c_uint32), ("src_stride", C.c_uint32), ("pred_stride", C.c_uint32),
+                ("src", C.c_void_p), ("pred", C.c_void_p), ("recon", C.c_void_p), ("jobs", C.c_void_p), ("quant_rows", C.c_void_p),
+                ("n_quant_rows", C.c_uint32),
+                ("eob", C.c_void_p), ("satd", C.c_void_p), ("dist_coeff", C.c_void_p), ("three_quad_energy", C.c_void_p), ("sse", C.c_void_p),
+                ("coeff", C.c_void_p), ("qcoeff", C.c_void_p), ("dqcoeff", C.c_void_p)]
+
+
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+JOB_DTYPE = [("src_offset", "<u4"), ("pred_offset", "<u4"), ("tx_type", "u1"), ("quant_row", "u1"), ("reserved", "u1", (2,))]
+QUANT_ROW_DTYPE = [(n, "<i2", (2,)) for n in ("zbin", "round", "quant", "quant_shift", "round_fp", "quant_fp", "dequant")]
+RD_OUT_FIELDS = [("eob", "<u2", 1), ("satd", "<u4", 1), ("dist_coeff", "<u8", 2), ("three_quad_energy", "<u8", 1), ("sse", "<u8", 1)]

@@ -1,0 +1,559 @@
+// rd_kernel.hip -- batched mode-decision RD evaluation on gfx950: one wave64 workgroup per transform block runs
+//   residual -> forward 2-D transform -> SATD -> quantize/dequantize (+eob) -> coefficient-domain distortion
+//   -> inverse 2-D transform + reconstruction -> pixel-domain SSE
+// i.e. one iteration of the reference's tx_type_search body (Source/Lib/Codec/product_coding_loop.c:4764-4934).
+//
+// Mapping: the W x H block lives in LDS as int32; a lane owns one column (then one row) of the separable
+// transform and keeps the whole 1-D vector in registers -- the butterfly networks are fully unrolled at compile
+// time from their structure (see dct_* below), so every register index and every cosine is a constant.  All
+// arithmetic is the reference's integer arithmetic (32-bit wrapping products, 64-bit rounding: half_btf,
+// Codec/inv_transforms.h:264-285), hence bit-exact.  Elementwise phases (quantizer, distortions) stride the block
+// across the 64 lanes and reduce with shuffles.  Memory traffic per block is the algorithmic minimum: source and
+// prediction read once, outputs written once (HBM-bound by design).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <type_traits>
+#include "svt_hip_internal.h"
+#include "../../include/svt_hip_dsp.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef long long          i64;
+
+__constant__ int32_t c_cospi[4][64]; // cospi_arr(bit), bit 10..13 (round(cos(j*pi/128) * 2^bit)), filled at init
+// svt_aom_eb_av1_sinpi_arr_data rows for cos_bit 10..13 (Codec/inv_transforms.c:3228-3234)
+__constant__ int32_t c_sinpi[4][5] = {{0, 330, 621, 836, 951}, {0, 660, 1241, 1672, 1901}, {0, 1321, 2482, 3344, 3803}, {0, 2642, 4964, 6689, 7606}};
+
+struct TxGeom { uint8_t w, h; };
+__host__ __device__ constexpr int tx_wide(int s) { constexpr uint8_t t[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64}; return t[s]; }
+__host__ __device__ constexpr int tx_high(int s) { constexpr uint8_t t[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16}; return t[s]; }
+__host__ __device__ constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
+__host__ __device__ constexpr int brevc(int v, int bits) { int r = 0; for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i); return r; }
+
+// fwd_txfm_shift_ls (Codec/transforms.h:27-45), fwd_cos_bit_col/row (:47-50), inv shifts (Codec/inv_transforms.c:17-35),
+// av1_get_tx_scale_tab (Codec/full_loop.h:53)
+__device__ const int8_t  c_fwd_shift[19][3] = {{2, 0, 0},  {2, -1, 0}, {2, -2, 0}, {2, -4, 0}, {0, -2, -2}, {2, -1, 0}, {2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {2, -4, 0},
+                                               {2, -4, 0}, {0, -2, -2}, {2, -4, -2}, {2, -1, 0}, {2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {0, -2, 0}, {2, -4, 0}};
+__device__ const int8_t  c_fwd_cos_col[5][5] = {{13, 13, 13, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 13, 12, 13}, {0, 13, 13, 12, 13}, {0, 0, 13, 12, 13}};
+__device__ const int8_t  c_fwd_cos_row[5][5] = {{13, 13, 12, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 12, 13, 12}, {0, 12, 13, 12, 11}, {0, 0, 12, 11, 10}};
+__device__ const int8_t  c_inv_shift0[19]    = {0, -1, -2, -2, -2, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1, -2, -2, -2, -2};
+__device__ const uint8_t c_log_scale[19]     = {0, 0, 0, 1, 2, 0, 0, 0, 0, 1, 1, 2, 2, 0, 0, 0, 0, 1, 1};
+// 1-D kernel of the column (vertical) / row (horizontal) pass per TxType: 0 DCT, 1 ADST, 2 FLIPADST, 3 identity (vtx_tab/htx_tab)
+__device__ const uint8_t c_vtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};
+__device__ const uint8_t c_htx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};
+
+__device__ __forceinline__ int32_t rshift64(i64 v, int bit) { return (int32_t)((v + ((i64)1 << (bit - 1))) >> bit); }
+__device__ __forceinline__ int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b, int bit) {
+    const i64 s = (i64)(int32_t)((uint32_t)w0 * (uint32_t)a) + (i64)(int32_t)((uint32_t)w1 * (uint32_t)b);
+    return (int32_t)((s + ((i64)1 << (bit - 1))) >> bit);
+}
+__device__ __forceinline__ int32_t clampv(i64 v, int bit) {
+    const i64 hi = ((i64)1 << (bit - 1)) - 1, lo = -((i64)1 << (bit - 1));
+    return (int32_t)(v < lo ? lo : (v > hi ? hi : v));
+}
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+
+// ---------------------------------------------------------------------------------------------------------
+// DCT flow graph, by structure.  x[M..2M) is the odd part of a 2M-point DCT:
+//   rotation stage k (k = 1..log2(M)-1): lanes in the middle half of every group of 2t (t = M >> k) are rotated
+//     with their mirror image (3M-1-p); angle (1 + 4*brev(group)) * (64 >> k); symmetric 2x2 blocks, so the same
+//     stage serves both directions;
+//   butterfly stage k: groups of t, even groups sum-first, odd groups difference-first;
+//   final stage: lane M+i with 2M-1-i, angle 64 - (2*brev(i)+1)*(32/M).
+// CLAMP < 0: forward transform (no clamps); otherwise the reference's clamp_value(stage_range) of the inverse.
+// ---------------------------------------------------------------------------------------------------------
+template <int M, int K> __device__ __forceinline__ void odd_rot(int32_t *x, const int32_t *c, int bit) {
+    constexpr int t = M >> K;
+    if constexpr (K == 1) {
+#pragma unroll
+        for (int j = 0; j < M / 4; j++) {
+            const int p = M + M / 4 + j, m = 3 * M - 1 - p;
+            const int32_t a = x[p], b = x[m];
+            x[p] = hbtf(-c[32], a, c[32], b, bit);
+            x[m] = hbtf(c[32], b, c[32], a, bit);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < (1 << (K - 2)); g++) {
+            const int A = (1 + 4 * brevc(g, K - 2)) * (64 >> K), B = 64 - A, base = M + g * 2 * t;
+#pragma unroll
+            for (int j = 0; j < t / 2; j++) {
+                const int p = base + t / 2 + j, m = 3 * M - 1 - p;
+                const int32_t a = x[p], b = x[m];
+                x[p] = hbtf(-c[A], a, c[B], b, bit);
+                x[m] = hbtf(c[A], b, c[B], a, bit);
+            }
+#pragma unroll
+            for (int j = 0; j < t / 2; j++) {
+                const int p = base + t + j, m = 3 * M - 1 - p;
+                const int32_t a = x[p], b = x[m];
+                x[p] = hbtf(-c[B], a, -c[A], b, bit);
+                x[m] = hbtf(c[B], b, -c[A], a, bit);
+            }
+        }
+    }
+}
+template <int M, int K, int CLAMP> __device__ __forceinline__ void odd_bfly(int32_t *x) {
+    constexpr int t = M >> K;
+#pragma unroll
+    for (int g = 0; g < M / t; g++) {
+#pragma unroll
+        for (int j = 0; j < t / 2; j++) {
+            const int i0 = M + g * t + j, i1 = M + g * t + t - 1 - j;
+            const int32_t lo = x[i0], hi = x[i1];
+            int32_t s, d;
+            if constexpr (CLAMP < 0) { s = wadd(lo, hi); d = (g & 1) ? wsub(hi, lo) : wsub(lo, hi); }
+            else { s = clampv((i64)lo + hi, CLAMP); d = clampv((g & 1) ? (i64)hi - lo : (i64)lo - hi, CLAMP); }
+            x[i0] = (g & 1) ? d : s;
+            x[i1] = (g & 1) ? s : d;
+        }
+    }
+}
+template <int M, bool INV> __device__ __forceinline__ void odd_final(int32_t *x, const int32_t *c, int bit) {
+#pragma unroll
+    for (int i = 0; i < M / 2; i++) {
+        const int A = 64 - (2 * brevc(i, ilog2c(M)) + 1) * (32 / M), B = 64 - A, p = M + i, m = 2 * M - 1 - i;
+        const int32_t a = x[p], b = x[m];
+        if constexpr (!INV) { x[p] = hbtf(c[A], a, c[B], b, bit); x[m] = hbtf(c[A], b, -c[B], a, bit); }
+        else { x[p] = hbtf(c[A], a, -c[B], b, bit); x[m] = hbtf(c[B], a, c[A], b, bit); }
+    }
+}
+template <int M, int K> struct OddFwd {
+    static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
+        if constexpr (K < ilog2c(M)) {
+            odd_rot<M, K>(x, c, bit);
+            odd_bfly<M, K, -1>(x);
+            OddFwd<M, K + 1>::run(x, c, bit);
+        }
+    }
+};
+template <int M, int K, int CLAMP> struct OddInv {
+    static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
+        if constexpr (K >= 1) {
+            odd_bfly<M, K, CLAMP>(x);
+            odd_rot<M, K>(x, c, bit);
+            OddInv<M, K - 1, CLAMP>::run(x, c, bit);
+        }
+    }
+};
+template <int N> __device__ __forceinline__ void fdct_core(int32_t *x, const int32_t *c, int bit) {
+    if constexpr (N == 2) {
+        const int32_t a = x[0], b = x[1];
+        x[0] = hbtf(c[32], a, c[32], b, bit);
+        x[1] = hbtf(-c[32], b, c[32], a, bit);
+    } else {
+        constexpr int M = N / 2;
+#pragma unroll
+        for (int i = 0; i < M; i++) { const int32_t a = x[i], b = x[N - 1 - i]; x[i] = wadd(a, b); x[N - 1 - i] = wsub(a, b); }
+        fdct_core<M>(x, c, bit);
+        OddFwd<M, 1>::run(x, c, bit);
+        odd_final<M, false>(x, c, bit);
+    }
+}
+template <int N, int CLAMP> __device__ __forceinline__ void idct_core(int32_t *x, const int32_t *c, int bit) {
+    if constexpr (N == 2) {
+        const int32_t a = x[0], b = x[1];
+        x[0] = hbtf(c[32], a, c[32], b, bit);
+        x[1] = hbtf(c[32], a, -c[32], b, bit);
+    } else {
+        constexpr int M = N / 2;
+        odd_final<M, true>(x, c, bit);
+        OddInv<M, ilog2c(M) - 1, CLAMP>::run(x, c, bit);
+        idct_core<M, CLAMP>(x, c, bit);
+#pragma unroll
+        for (int i = 0; i < M; i++) { const int32_t a = x[i], b = x[N - 1 - i]; x[i] = clampv((i64)a + b, CLAMP); x[N - 1 - i] = clampv((i64)a - b, CLAMP); }
+    }
+}
+template <int N> __device__ __forceinline__ void permute_brev(int32_t *x) { // out[k] = in[brev(k)]: an involution, swap pairs
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int r = brevc(k, ilog2c(N));
+        if (r > k) { const int32_t t = x[k]; x[k] = x[r]; x[r] = t; }
+    }
+}
+
+// ---- ADST 8 / 16 (svt_av1_fadst8/16_new, iadst8/16_new) and ADST 4 ----
+template <int N> __host__ __device__ constexpr int adst_perm(int k) { // P_N[2j] = P_{N/2}[j], P_N[2j+1] = N-1-P_{N/2}[j], P_2 = {0,1}
+    if constexpr (N == 2) return k;
+    else return (k & 1) ? N - 1 - adst_perm<N / 2>(k >> 1) : adst_perm<N / 2>(k >> 1);
+}
+template <int N, int HH> __device__ __forceinline__ void adst_rot(int32_t *x, const int32_t *c, int bit) {
+#pragma unroll
+    for (int b = 0; b < N; b += 2 * HH) {
+        if constexpr (HH == 2) {
+            const int32_t a = x[b + 2], d = x[b + 3];
+            x[b + 2] = hbtf(c[32], a, c[32], d, bit);
+            x[b + 3] = hbtf(c[32], a, -c[32], d, bit);
+        } else {
+#pragma unroll
+            for (int j = 0; j < HH / 4; j++) {
+                const int A = (4 * j + 1) * (64 / HH), B = 64 - A, p = b + HH + 2 * j, q = b + HH + HH / 2 + 2 * j;
+                int32_t a = x[p], d = x[p + 1];
+                x[p]     = hbtf(c[A], a, c[B], d, bit);
+                x[p + 1] = hbtf(c[B], a, -c[A], d, bit);
+                a = x[q]; d = x[q + 1];
+                x[q]     = hbtf(-c[B], a, c[A], d, bit);
+                x[q + 1] = hbtf(c[A], a, c[B], d, bit);
+            }
+        }
+    }
+}
+template <int N, int HH, int CLAMP> __device__ __forceinline__ void adst_bfly(int32_t *x) {
+#pragma unroll
+    for (int b = 0; b < N; b += 2 * HH)
+#pragma unroll
+        for (int j = 0; j < HH; j++) {
+            const int32_t a = x[b + j], d = x[b + j + HH];
+            if constexpr (CLAMP < 0) { x[b + j] = wadd(a, d); x[b + j + HH] = wsub(a, d); }
+            else { x[b + j] = clampv((i64)a + d, CLAMP); x[b + j + HH] = clampv((i64)a - d, CLAMP); }
+        }
+}
+template <int N> __device__ __forceinline__ void adst_last(int32_t *x, const int32_t *c, int bit) {
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) {
+        const int A = (4 * j + 1) * (64 / (2 * N)), B = 64 - A;
+        const int32_t a = x[2 * j], d = x[2 * j + 1];
+        x[2 * j]     = hbtf(c[A], a, c[B], d, bit);
+        x[2 * j + 1] = hbtf(c[B], a, -c[A], d, bit);
+    }
+}
+template <int N, int HH> struct AdstFwd {
+    static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
+        if constexpr (HH < N) { adst_rot<N, HH>(x, c, bit); adst_bfly<N, HH, -1>(x); AdstFwd<N, HH * 2>::run(x, c, bit); }
+    }
+};
+template <int N, int HH, int CLAMP> struct AdstInv {
+    static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
+        if constexpr (HH >= 2) { adst_bfly<N, HH, CLAMP>(x); adst_rot<N, HH>(x, c, bit); AdstInv<N, HH / 2, CLAMP>::run(x, c, bit); }
+    }
+};
+template <int N> __device__ __forceinline__ void fadst(int32_t *x, const int32_t *c, int bit) {
+    int32_t y[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { const int32_t v = x[adst_perm<N>(k)]; y[k] = (__builtin_popcount(k) & 1) ? (int32_t)(0u - (uint32_t)v) : v; }
+    AdstFwd<N, 2>::run(y, c, bit);
+    adst_last<N>(y, c, bit);
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) { x[2 * j] = y[2 * j + 1]; x[2 * j + 1] = y[N - 2 - 2 * j]; }
+}
+template <int N, int CLAMP> __device__ __forceinline__ void iadst(int32_t *x, const int32_t *c, int bit) {
+    int32_t y[N];
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) { y[2 * j + 1] = x[2 * j]; y[N - 2 - 2 * j] = x[2 * j + 1]; }
+    adst_last<N>(y, c, bit);
+    AdstInv<N, N / 2, CLAMP>::run(y, c, bit);
+#pragma unroll
+    for (int k = 0; k < N; k++) x[adst_perm<N>(k)] = (__builtin_popcount(k) & 1) ? (int32_t)(0u - (uint32_t)y[k]) : y[k];
+}
+#define MUL32(a, b) ((int32_t)((uint32_t)(a) * (uint32_t)(b)))
+__device__ __forceinline__ void adst4(int32_t *x, int bit, bool inverse) { // transforms.c:1415-1503, inv_transforms.c:722-806
+    const int32_t *s = c_sinpi[bit - 10];
+    const int32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    if (!(x0 | x1 | x2 | x3)) return;
+    if (!inverse) {
+        const int32_t s7 = wsub(wadd(x0, x1), x3);
+        const int32_t a0 = wadd(wadd(MUL32(s[1], x0), MUL32(s[2], x1)), MUL32(s[4], x3)), a1 = MUL32(s[3], s7);
+        const int32_t a2 = wadd(wsub(MUL32(s[4], x0), MUL32(s[1], x1)), MUL32(s[2], x3)), a3 = MUL32(s[3], x2);
+        x[0] = rshift64(wadd(a0, a3), bit); x[1] = rshift64(a1, bit); x[2] = rshift64(wsub(a2, a3), bit); x[3] = rshift64(wadd(wsub(a2, a0), a3), bit);
+    } else {
+        const int32_t s7 = wadd(wsub(x0, x2), x3);
+        const int32_t a0 = wadd(wadd(MUL32(s[1], x0), MUL32(s[4], x2)), MUL32(s[2], x3));
+        const int32_t a1 = wsub(wsub(MUL32(s[2], x0), MUL32(s[1], x2)), MUL32(s[4], x3)), a3 = MUL32(s[3], x1), a2 = MUL32(s[3], s7);
+        x[0] = rshift64(wadd(a0, a3), bit); x[1] = rshift64(wadd(a1, a3), bit); x[2] = rshift64(a2, bit); x[3] = rshift64(wsub(wadd(a0, a1), a3), bit);
+    }
+}
+template <int N> __device__ __forceinline__ void identity(int32_t *x) { // transforms.c:2205-2236, inv_transforms.c:2331-2363
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if constexpr (N == 4) x[i] = rshift64((i64)x[i] * 5793, 12);
+        else if constexpr (N == 8) x[i] = (int32_t)((uint32_t)x[i] * 2u);
+        else if constexpr (N == 16) x[i] = rshift64((i64)x[i] * 2 * 5793, 12);
+        else if constexpr (N == 32) x[i] = (int32_t)((uint32_t)x[i] * 4u);
+        else x[i] = rshift64((i64)x[i] * 4 * 5793, 12);
+    }
+}
+// 1-D dispatch: type 0 DCT, 1/2 ADST (flips are applied by the 2-D passes), 3 identity.  Wave-uniform switch.
+template <int N> __device__ __forceinline__ void fwd_1d(int32_t *x, int type, int bit) {
+    const int32_t *c = c_cospi[bit - 10];
+    if (type == 3) identity<N>(x);
+    else if (type == 0) { fdct_core<N>(x, c, bit); permute_brev<N>(x); }
+    else if constexpr (N == 4) adst4(x, bit, false);
+    else if constexpr (N <= 16) fadst<N>(x, c, bit);
+}
+template <int N, int CLAMP> __device__ __forceinline__ void inv_1d(int32_t *x, int type) {
+    const int32_t *c = c_cospi[2]; // INV_COS_BIT = 12
+    if (type == 3) identity<N>(x);
+    else if (type == 0) { permute_brev<N>(x); idct_core<N, CLAMP>(x, c, 12); }
+    else if constexpr (N == 4) adst4(x, 12, true);
+    else if constexpr (N <= 16) iadst<N, CLAMP>(x, c, 12);
+}
+template <int N> __device__ __forceinline__ void shift_vec(int32_t *x, int sh) { // svt_av1_round_shift_array_c(x, N, -sh)
+    if (sh < 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = rshift64(x[i], -sh);
+    } else if (sh > 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = (int32_t)((uint32_t)x[i] << sh);
+    }
+}
+
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+
+struct RdParams {
+    SvtHipRdBatchDesc d;
+    const int16_t    *iscan[3]; // default, row (V_*), column (H_*) scans of this tx_size
+    int               tx_size;
+};
+
+template <typename T> __device__ __forceinline__ int ldpix(const void *p, size_t i) { return (int)static_cast<const T *>(p)[i]; }
+
+// =========================================================================================================
+template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(const RdParams p) {
+    constexpr int W = tx_wide(TS), H = tx_high(TS), WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
+    constexpr int ROW_CLAMP = BD == 8 ? 16 : 18, COL_CLAMP = 16; // svt_av1_gen_inv_stage_range, inv_transforms.c:42-80
+    constexpr bool RECT = (W == 2 * H || H == 2 * W);
+    using Pix = typename std::conditional<BD == 8, uint8_t, uint16_t>::type;
+    __shared__ int32_t A[W * H], B[W * H];
+    const int          lane = threadIdx.x;
+    const uint32_t     job  = blockIdx.x;
+    if (job >= p.d.n_jobs) return;
+    const SvtHipTxJob jb = p.d.jobs[job];
+    const int tt = jb.tx_type & 15, vt = c_vtx[tt], ht = c_htx[tt];
+    const bool ud = (vt == 2), lr = (ht == 2);
+    const Pix *src  = static_cast<const Pix *>(p.d.src) + jb.src_offset;
+    const Pix *pred = static_cast<const Pix *>(p.d.pred) + jb.pred_offset;
+    const int8_t *fsh = c_fwd_shift[TS];
+    const int bit_col = c_fwd_cos_col[ilog2c(W) - 2][ilog2c(H) - 2], bit_row = c_fwd_cos_row[ilog2c(W) - 2][ilog2c(H) - 2];
+
+    // residual (svt_residual_kernel8bit / 16bit): int16 arithmetic as in the reference
+    for (int i = lane; i < W * H; i += 64) {
+        const int r = i / W, c = i - r * W;
+        A[i] = (int16_t)((int16_t)src[(size_t)r * p.d.src_stride + c] - (int16_t)pred[(size_t)r * p.d.pred_stride + c]);
+    }
+    __syncthreads();
+    // forward columns (av1_tranform_two_d_core_c, transforms.c:2287-2308)
+    if (lane < W) {
+        int32_t x[H];
+#pragma unroll
+        for (int r = 0; r < H; r++) x[r] = A[(ud ? H - 1 - r : r) * W + lane];
+        shift_vec<H>(x, fsh[0]);
+        fwd_1d<H>(x, vt, bit_col);
+        shift_vec<H>(x, fsh[1]);
+        const int oc = lr ? W - 1 - lane : lane;
+#pragma unroll
+        for (int r = 0; r < H; r++) B[r * W + oc] = x[r];
+    }
+    __syncthreads();
+    // forward rows (:2310-2323)
+    if (lane < H) {
+        int32_t x[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) x[c] = B[lane * W + c];
+        fwd_1d<W>(x, ht, bit_row);
+        shift_vec<W>(x, fsh[2]);
+        if constexpr (RECT) {
+#pragma unroll
+            for (int c = 0; c < W; c++) x[c] = rshift64((i64)x[c] * 5793, 12);
+        }
+#pragma unroll
+        for (int c = 0; c < W; c++) A[lane * W + c] = x[c];
+    }
+    __syncthreads();
+    // 64-point sizes keep the top-left 32x32 (svt_handle_transform*_c, transforms.c:2374-2505)
+    u64 tq = 0;
+    if constexpr (W > 32 || H > 32) {
+        for (int i = lane; i < W * H; i += 64) {
+            const int r = i / W, c = i - r * W;
+            if (r >= HP || c >= WP) tq += (u64)((i64)A[i] * A[i]);
+        }
+        tq = wave_sum_u64(tq);
+    }
+    // SATD, quantize, coefficient-domain distortion over the kept NP coefficients (packed index rc = r*WP + c)
+    const SvtHipQuantRow q = p.d.quant_rows[jb.quant_row];
+    const int     log_scale = c_log_scale[TS];
+    const int16_t *iscan    = p.iscan[(tt >= 10) ? ((tt & 1) ? 2 : 1) : 0];
+    uint32_t satd = 0, eob = 0;
+    u64      dres = 0, dpred = 0;
+    int32_t *co_out = p.d.coeff ? p.d.coeff + (size_t)job * NP : nullptr;
+    int32_t *q_out  = p.d.qcoeff ? p.d.qcoeff + (size_t)job * NP : nullptr;
+    int32_t *dq_out = p.d.dqcoeff ? p.d.dqcoeff + (size_t)job * NP : nullptr;
+    for (int rc = lane; rc < NP; rc += 64) {
+        const int r = rc / WP, c = rc - r * WP, ac = rc != 0;
+        const int32_t co = A[r * W + c], sign = co < 0 ? -1 : 0, a = (co ^ sign) - sign;
+        satd += (uint32_t)a;
+        int32_t qv = 0, dq = 0;
+        if (p.d.quant_kind == 0) { // svt_aom_quantize_b_c_ii / svt_aom_highbd_quantize_b_c without a quantization matrix
+            const int32_t zb = log_scale ? ((q.zbin[ac] + (1 << (log_scale - 1))) >> log_scale) : q.zbin[ac];
+            if (a >= zb) {
+                i64 t = (i64)a + (log_scale ? ((q.round[ac] + (1 << (log_scale - 1))) >> log_scale) : q.round[ac]);
+                if (BD == 8) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+                t *= 32; // wt = 1 << AOM_QM_BITS
+                qv = (int32_t)(((((t * q.quant[ac]) >> 16) + t) * q.quant_shift[ac]) >> (16 - log_scale + 5));
+                dq = (qv * (int32_t)q.dequant[ac]) >> log_scale;
+            }
+        } else { // quantize_fp_helper_c / highbd_quantize_fp_helper_c
+            const bool keep = (BD == 8) ? (((i64)a << (1 + log_scale)) >= (int32_t)q.dequant[ac]) : ((a << (1 + log_scale)) >= q.dequant[ac]);
+            if (keep) {
+                i64 t = (i64)a + (log_scale ? ((q.round_fp[ac] + (1 << (log_scale - 1))) >> log_scale) : q.round_fp[ac]);
+                if (BD == 8) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+                qv = (int32_t)((t * q.quant_fp[ac]) >> (16 - log_scale));
+                dq = (qv * (int32_t)q.dequant[ac]) >> log_scale;
+            }
+        }
+        const int32_t qs = (qv ^ sign) - sign, dqs = (dq ^ sign) - sign;
+        if (qv) { const uint32_t e = (uint32_t)iscan[rc] + 1; eob = e > eob ? e : eob; }
+        const i64 dd = (i64)co - dqs;
+        dres += (u64)(dd * dd);
+        dpred += (u64)((i64)co * co);
+        B[rc] = dqs; // packed dequantized coefficients feed the inverse transform
+        if (co_out) co_out[rc] = co;
+        if (q_out) q_out[rc] = qs;
+        if (dq_out) dq_out[rc] = dqs;
+    }
+    satd  = wave_sum_u32(satd);
+    eob   = wave_max_u32(eob);
+    dres  = wave_sum_u64(dres);
+    dpred = wave_sum_u64(dpred);
+    __syncthreads();
+    // inverse rows (inv_txfm2d_add_c, inv_transforms.c:2497-2511): discarded frequencies are zero
+    if (lane < H) {
+        int32_t x[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t v = (lane < HP && c < WP) ? B[lane * WP + c] : 0;
+            if constexpr (RECT) v = rshift64((i64)v * 2896, 12);
+            x[c] = clampv(v, BD + 8);
+        }
+        inv_1d<W, ROW_CLAMP>(x, ht);
+        shift_vec<W>(x, c_inv_shift0[TS]);
+#pragma unroll
+        for (int c = 0; c < W; c++) A[lane * W + c] = x[c];
+    }
+    __syncthreads();
+    // inverse columns + reconstruction + SSE (:2513-2534; svt_spatial_full_distortion_kernel / 16-bit variant)
+    u64 sse = 0;
+    if (lane < W) {
+        int32_t x[H];
+        const int ic = lr ? W - 1 - lane : lane;
+#pragma unroll
+        for (int r = 0; r < H; r++) x[r] = clampv(A[r * W + ic], BD + 6 > 16 ? BD + 6 : 16);
+        inv_1d<H, COL_CLAMP>(x, vt);
+        shift_vec<H>(x, -4);
+        Pix *rec = p.d.recon ? static_cast<Pix *>(p.d.recon) + jb.pred_offset : nullptr;
+#pragma unroll
+        for (int r = 0; r < H; r++) {
+            const int res = x[ud ? H - 1 - r : r];
+            int v = (int)pred[(size_t)r * p.d.pred_stride + lane] + res;
+            v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
+            if (rec) rec[(size_t)r * p.d.pred_stride + lane] = (Pix)v;
+            const i64 e = (i64)src[(size_t)r * p.d.src_stride + lane] - v;
+            sse += (u64)(e * e);
+        }
+    }
+    sse = wave_sum_u64(sse);
+    if (lane == 0) {
+        p.d.eob[job]  = (uint16_t)eob;
+        p.d.satd[job] = satd;
+        p.d.dist_coeff[2 * (size_t)job]     = dres;
+        p.d.dist_coeff[2 * (size_t)job + 1] = dpred;
+        p.d.three_quad_energy[job] = tq;
+        p.d.sse[job]  = sse;
+    }
+}
+
+template <int BD> int launch_size(SvtHipContext *ctx, const RdParams &p) {
+    const dim3 g(p.d.n_jobs), b(64);
+#define CASE(S) case S: hipLaunchKernelGGL((rd_tx_kernel<S, BD>), g, b, 0, ctx->stream, p); break;
+    switch (p.tx_size) {
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+    default: return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %d", p.tx_size);
+    }
+#undef CASE
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+// host-side scan order generator (av1_scan_orders, Codec/coefficients.h:2197): diagonal scan for 2-D types and IDTX
+// (zig-zag on square blocks, single-direction diagonals on rectangular ones), row scan for V_*, column scan for H_*
+int scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
+    const int w = tx_wide(tx_size) > 32 ? 32 : tx_wide(tx_size), h = tx_high(tx_size) > 32 ? 32 : tx_high(tx_size), n = w * h;
+    int k = 0;
+    if (tx_type >= 10 && (tx_type & 1) == 0) { for (int i = 0; i < n; i++) scan[k++] = (int16_t)i; }
+    else if (tx_type >= 11) { for (int c = 0; c < w; c++) for (int r = 0; r < h; r++) scan[k++] = (int16_t)(r * w + c); }
+    else
+        for (int d = 0; d < w + h - 1; d++) {
+            const int down = (w < h) ? 1 : (w > h) ? 0 : (d & 1);
+            for (int i = 0; i <= d; i++) { const int r = down ? i : d - i, c = d - r; if (r < h && c < w) scan[k++] = (int16_t)(r * w + c); }
+        }
+    for (int i = 0; i < n; i++) iscan[scan[i]] = (int16_t)i;
+    return n;
+}
+
+int16_t *g_iscan_dev = nullptr; // [19][3][1024] inverse scans, device resident
+bool     g_tables_ready = false;
+
+int init_tables(SvtHipContext *ctx) {
+    if (g_tables_ready) return SVT_HIP_OK;
+    static int32_t cosp[4][64];
+    for (int b = 0; b < 4; b++)
+        for (int j = 0; j < 64; j++) cosp[b][j] = (int32_t)(cos(3.14159265358979323846 * j / 128.0) * (double)(1 << (10 + b)) + 0.5);
+    SVT_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_cospi), cosp, sizeof(cosp)));
+    static int16_t tab[19][3][1024], scan[1024];
+    memset(tab, 0, sizeof(tab));
+    for (int s = 0; s < 19; s++)
+        for (int kind = 0; kind < 3; kind++) scan_order(s, kind == 0 ? 0 : (kind == 1 ? 10 : 11), scan, tab[s][kind]);
+    if (hipMalloc(reinterpret_cast<void **>(&g_iscan_dev), sizeof(tab)) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "iscan tables");
+    SVT_HIP_CHECK(ctx, hipMemcpy(g_iscan_dev, tab, sizeof(tab), hipMemcpyHostToDevice));
+    g_tables_ready = true;
+    return SVT_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int svt_hip_tx_size_wide(int tx_size) { return (tx_size >= 0 && tx_size < 19) ? tx_wide(tx_size) : 0; }
+int svt_hip_tx_size_high(int tx_size) { return (tx_size >= 0 && tx_size < 19) ? tx_high(tx_size) : 0; }
+
+int svt_hip_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
+    if (tx_size < 0 || tx_size >= 19 || tx_type < 0 || tx_type >= 16 || !scan || !iscan) return 0;
+    return scan_order(tx_size, tx_type, scan, iscan);
+}
+
+int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d) {
+    if (!ctx || !d) return SVT_HIP_ERR_BAD_PARAM;
+    if (d->n_jobs == 0) return SVT_HIP_OK;
+    if ((d->bit_depth != 8 && d->bit_depth != 10) || d->quant_kind > 1)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "bit_depth %u / quant_kind %u", d->bit_depth, d->quant_kind);
+    if (!d->src || !d->pred || !d->jobs || !d->quant_rows || !d->eob || !d->satd || !d->dist_coeff || !d->three_quad_energy || !d->sse)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the RD batch is null");
+    hipSetDevice(ctx->device);
+    int rc = init_tables(ctx);
+    if (rc) return rc;
+    RdParams p;
+    p.d       = *d;
+    p.tx_size = d->tx_size;
+    if (p.tx_size < 0 || p.tx_size >= 19) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %d", p.tx_size);
+    for (int k = 0; k < 3; k++) p.iscan[k] = g_iscan_dev + ((size_t)p.tx_size * 3 + k) * 1024;
+    return d->bit_depth == 8 ? launch_size<8>(ctx, p) : launch_size<10>(ctx, p);
+}
+
+} // extern "C"
