@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- ME + RD-cost throughput of the MI355X backend on synthetic 2160p 10-bit pictures, preset 6.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A *step* = one mini-GOP slice of 4 pictures of the sequence (reference distances 1, 2, 4, 8; temporal layers 4..1;
+R = 2 references per picture, one per list), each going through
+  1. open-loop ME for every 64x64 block (svt_hip_me_picture_async == N x svt_aom_motion_estimation_b64),
+  2. full-pel motion-compensated 10-bit prediction from the ME winners (svt_hip_fullpel_pred),
+  3. the RD kernels on the 10-bit luma at three transform depths (64x64, 32x32, 16x16, DCT_DCT, "b" quantizer):
+     residual -> fwd txfm -> SATD -> quantize -> coeff distortion -> inv txfm -> SSE (svt_hip_rd_batch).
+With N GPUs the b64 rows of every picture are sharded across the ranks (all planes are replicated; no halo
+exchange) and the per-b64 ME results are all-gathered over RCCL once per step -- the exchange north_star names.
+`value` = luma pixels of the pictures fully processed per second, whole job (strong scaling: the pictures per step
+are fixed, each rank handles 1/N of the b64 rows).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from svt_av1_psyex_amd import abi, api, rd, synth  # noqa: E402
+
+W, H = 3840, 2160
+DISTS = (1, 2, 4, 8)
+LAYER = {1: 4, 2: 3, 4: 2, 8: 1}
+CUR = 8
+N_FRAMES = 17
+RD_SIZES = (4, 3, 2)  # TX_64X64, TX_32X32, TX_16X16
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class Workload:
+    """Device-resident inputs and per-step launch plan for one rank."""
+
+    def __init__(self, ctx, rank, world, seed=11):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        t0 = time.time()
+        y10 = synth.synth_sequence(W, H, N_FRAMES, seed)
+        y8 = synth.to_8bit(y10)
+        self.host8 = {i: synth.HostPyramid(y8[i], i) for i in range(N_FRAMES)}
+        self.y10_host = y10
+        self.pics = {i: ctx.upload(self.host8[i]) for i in range(N_FRAMES)}
+        self.y10 = {i: torch.from_numpy(y10[i].astype(np.int16)).cuda().view(torch.int16) for i in (CUR,) + tuple(CUR - d for d in DISTS)}
+        self.w64, self.h64 = (W + 63) // 64, (H + 63) // 64
+        # contiguous b64 row band of this rank
+        self.row0 = (self.h64 * rank) // world
+        self.row1 = (self.h64 * (rank + 1)) // world
+        self.cfgs, self.descs = {}, {}
+        for d in DISTS:
+            self.cfgs[d] = api.config_from_preset(6, W, H, qp=35, temporal_layer_index=LAYER[d], hierarchical_levels=4)
+            desc = api.picture_desc(W, H, CUR, {(0, 0): CUR - d, (1, 0): CUR + d}, enc_mode=6, temporal_layer_index=LAYER[d], hierarchical_levels=4)
+            desc.b64_row_start, desc.b64_row_count = self.row0, self.row1 - self.row0
+            self.descs[d] = desc
+        self.n_pu = abi.n_pu(desc.enable_me_16x16, desc.enable_me_8x8)
+        # ME results of the 4 pictures of a step: ONE compact device buffer holding only this rank's b64 rows (padded to
+        # the largest band so every rank contributes the same byte count to the all-gather).  The kernel indexes its
+        # outputs by absolute b64 index, so each field pointer is biased back by the band's first row.
+        rows_max = -(-self.h64 // world)
+        nbb = rows_max * self.w64
+        self.me_fields = [(n, dt, c(self.n_pu, desc.max_refs, desc.max_cand)) for n, dt, c in abi.RESULT_FIELDS if n not in ("hme_sc", "hme_sad", "do_ref")]
+        self.me_bytes_per_b64 = sum(np.dtype(dt).itemsize * c for _, dt, c in self.me_fields)
+        self.me_buf = torch.zeros(len(DISTS) * nbb * self.me_bytes_per_b64, dtype=torch.uint8, device="cuda")
+        self.me_res, self.mv_ptr = {}, {}
+        off = 0
+        first = self.row0 * self.w64
+        for d in DISTS:
+            res = abi.MeResults()
+            for name, dt, c in self.me_fields:
+                per = np.dtype(dt).itemsize * c
+                setattr(res, name, self.me_buf.data_ptr() + off - first * per)
+                if name == "sb_best_mv":
+                    self.mv_ptr[d] = self.me_buf.data_ptr() + off - first * per
+                off += nbb * per
+            self.me_res[d] = res
+        # RD: prediction / recon planes and job lists restricted to this rank's rows
+        self.pred = torch.zeros(H * W, dtype=torch.int16, device="cuda")
+        self.recon = torch.zeros(H * W, dtype=torch.int16, device="cuda")
+        self.rows = torch.from_numpy(np.stack([rd.quant_row_from_step(140, 176)]).view(np.uint8).reshape(-1)).cuda()
+        y_lo, y_hi = self.row0 * 64, min(self.row1 * 64, H)
+        self.rd = []
+        self.rd_pixels = 0
+        for ts in RD_SIZES:
+            jobs = rd.grid_jobs(W, H, W, ts)
+            ys = (jobs["src_offset"] // W).astype(np.int64)
+            keep = (ys >= y_lo) & (ys < y_hi)  # bands are whole b64 rows, so a block never straddles two ranks
+            jobs = np.ascontiguousarray(jobs[keep])
+            n = len(jobs)
+            t_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).cuda()
+            outs = {name: torch.zeros(max(n, 1) * k * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt, k in abi.RD_OUT_FIELDS}
+            d = abi.RdBatchDesc(bit_depth=10, quant_kind=0, tx_size=ts, n_jobs=n, src_stride=W, pred_stride=W, src=self.y10[CUR].data_ptr(),
+                                pred=self.pred.data_ptr(), recon=self.recon.data_ptr(), jobs=t_jobs.data_ptr(), quant_rows=self.rows.data_ptr(), n_quant_rows=1)
+            for name, t in outs.items():
+                setattr(d, name, t.data_ptr())
+            self.rd.append((ts, d, t_jobs, outs, n))
+            self.rd_pixels += n * abi.TX_W[ts] * abi.TX_H[ts]
+        torch.cuda.synchronize()
+        log(f"[rank {rank}] setup {time.time() - t0:.1f}s: rows {self.row0}..{self.row1} of {self.h64}, RD jobs {[r[4] for r in self.rd]}")
+
+    def refs(self, d):
+        return {(0, 0): self.pics[CUR - d], (1, 0): self.pics[CUR + d]}
+
+    def step(self, ev=None):
+        """Enqueue one step on the context stream.  `ev`: optional dict collecting (start, end) event pairs per kernel family."""
+        L = api.lib()
+        for d in DISTS:
+            if ev is not None:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            self.ctx.me_picture_async(self.cfgs[d], self.descs[d], self.pics[CUR], self.refs(d), self.me_res[d])
+            if ev is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record(); ev["me"].append((e0, e1))
+            self.ctx.check(L.svt_hip_fullpel_pred(self.ctx._h, C.c_void_p(self.y10[CUR - d].data_ptr()), W, W, H, 10, C.c_void_p(self.mv_ptr[d]), 0, 0,
+                                                  self.row0, self.row1 - self.row0, C.c_void_p(self.pred.data_ptr()), W), "svt_hip_fullpel_pred")
+            if ev is not None:
+                e2 = torch.cuda.Event(enable_timing=True); e2.record(); ev["pred"].append((e1, e2))
+            for ts, desc, _, _, n in self.rd:
+                if n:
+                    self.ctx.check(L.svt_hip_rd_batch(self.ctx._h, C.byref(desc)), "svt_hip_rd_batch")
+            if ev is not None:
+                e3 = torch.cuda.Event(enable_timing=True); e3.record(); ev["rd"].append((e2, e3))
+
+
+def cpu_baseline(wl, seconds_target=12.0):
+    """The oracle (C restatement, bit-exact to the reference `_c` path; oracle/) on the host cores: ME on a band of b64
+    rows + the RD chain on the same rows, all cores via one thread per row group (ctypes releases the GIL)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import concurrent.futures as cf
+    import pyoracle
+    cores = min(os.cpu_count() or 1, 16)
+    rows_total = cores  # one b64 row per thread
+    row_start = wl.h64 // 2 - rows_total // 2
+    d = 2
+    cfg = wl.cfgs[d]
+    src10 = wl.y10_host[CUR]
+    pred10 = wl.y10_host[CUR - d]
+    qrows = np.stack([rd.quant_row_from_step(140, 176)])
+
+    def work(row):
+        desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[d]))
+        desc.b64_row_start, desc.b64_row_count = row, 1
+        pyoracle.me_picture("oracle", cfg, desc, wl.host8[CUR], {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}, search_level=False)
+        for ts in RD_SIZES:
+            jobs = rd.grid_jobs(W, H, W, ts)
+            ys = jobs["src_offset"] // W
+            jobs = np.ascontiguousarray(jobs[(ys >= row * 64) & (ys < row * 64 + 64)])
+            rd.run_oracle(dict(bit_depth=10, quant_kind=0, tx_size=ts, src_stride=W, pred_stride=W), src10, pred10, jobs, qrows, want_coeffs=False, want_recon=False)
+
+    pyoracle.load_oracle()
+    t0 = time.time()
+    reps = 0
+    while True:
+        with cf.ThreadPoolExecutor(cores) as ex:
+            list(ex.map(work, range(row_start, row_start + rows_total)))
+        reps += 1
+        if time.time() - t0 > seconds_target or reps >= 8:
+            break
+    dt = time.time() - t0
+    pixels = reps * rows_total * 64 * W
+    out = {"value": round(pixels / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+           "sample": f"{reps} x {rows_total} b64 rows ({rows_total * 64}x{W} px) of the 2160p distance-2 picture: oracle ME (R=2) + RD chain at 3 depths"}
+    # informational: the reference's own AVX2 ME kernels (oracle/_ref, SAD path only), same rows, same threads
+    if pyoracle.ref_available():
+        try:
+            ref = pyoracle.load_ref()
+            if ref.ref_has_avx2():
+                ref.ref_set_simd(1)
+
+                def work_ref(row):
+                    desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[d]))
+                    desc.b64_row_start, desc.b64_row_count = row, 1
+                    pyoracle.me_picture("ref", cfg, desc, wl.host8[CUR], {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}, search_level=False)
+                t1 = time.time()
+                with cf.ThreadPoolExecutor(cores) as ex:
+                    list(ex.map(work_ref, range(row_start, row_start + rows_total)))
+                out["reference_avx2_me_only_mpixels_s"] = round(rows_total * 64 * W / (time.time() - t1) / 1e6, 2)
+                ref.ref_set_simd(0)
+        except Exception as e:  # informational only
+            out["reference_avx2_me_only_error"] = str(e)[:100]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        log(f"--gpus {a.gpus} but WORLD_SIZE {world}: running with world size {world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = api.Context(local_rank)
+    ext = torch.cuda.ExternalStream(ctx.stream)
+    wl = Workload(ctx, rank, world)
+    gather_out = torch.zeros(world * wl.me_buf.numel(), dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    def run(steps, ev=None):
+        with torch.cuda.stream(ext):
+            for _ in range(steps):
+                wl.step(ev)
+                if world > 1:
+                    # per-b64 best-cost / MV / candidate results of this rank's rows -> every rank (RCCL over xGMI)
+                    dist.all_gather_into_tensor(gather_out, wl.me_buf)
+
+    run(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    # kernel-level durations (HIP events on the launch stream), separate short pass so events do not perturb the timed loop
+    ev = {"me": [], "pred": [], "rd": []}
+    run(min(a.steps, 3), ev)
+    barrier()
+    kms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in ev.items()}
+    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    dt = float(t_all.item())
+    pictures = a.steps * len(DISTS)
+    value = pictures * W * H / dt / 1e6
+    if rank == 0:
+        R = 2
+        frac_rows = (wl.row1 - wl.row0) / wl.h64
+        me_bytes = (1.3125 * (1 + R) + 0.166 * R) * W * H * frac_rows  # B_ME bytes per pixel
+        rd_bytes = wl.rd_pixels * (2 * 2 + 4 + 2)  # B_RD = 2*bpp + 4 (+bpp recon), bpp = 2
+        dom = "me" if kms["me"] >= kms["rd"] else "rd"
+        ach = (me_bytes if dom == "me" else rd_bytes) / (kms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "ME+RD-cost Mpixels/s (2160p10 preset-6)", "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8 SAD / i32 transforms", "data": "synthetic",
+            "config": {"workload": "3840x2160 10-bit synthetic pan sequence, preset 6 (M6) search controls at qp 35; step = 4 pictures (ref distance 1,2,4,8; R=2): "
+                                   "open-loop ME of all 2040 b64 + full-pel pred + RD chain (64x64,32x32,16x16 DCT_DCT, 10-bit, b quantizer)",
+                       "pictures_per_step": len(DISTS), "b64_rows_per_rank": wl.row1 - wl.row0, "parallelism": f"b64-row bands x{world} + all-gather of ME results"},
+            "roofline": {"bound": "hbm", "kernel": "svt_hip_me_b64_kernel" if dom == "me" else "rd_tx_kernel (3 sizes)", "achieved": round(ach, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(me_bytes if dom == "me" else rd_bytes), "avg_launch_ms": round(kms[dom], 4)},
+            "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

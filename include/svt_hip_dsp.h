@@ -68,6 +68,14 @@ typedef struct SvtHipRdBatchDesc {
  * Returns non-zero (and leaves nothing enqueued) when the descriptor fails validation. */
 int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d);
 
+/* Full-pel motion-compensated prediction from ME results: every 16x16 PU copies the block of `ref` displaced by its
+ * best integer MV (sb_best_mv = SvtHipMeResults.sb_best_mv, device pointer; list / ref_idx select the reference).
+ * ref / pred are device planes of `bit_depth` 8 (uint8) or 10 (uint16), strides in samples, no padding needed
+ * (coordinates are clamped to the picture).  The integer-MV case of inter prediction; feeds svt_hip_rd_batch. */
+int svt_hip_fullpel_pred(SvtHipContext *ctx, const void *ref, uint32_t ref_stride, uint32_t width, uint32_t height, uint8_t bit_depth,
+                         const uint32_t *sb_best_mv, uint8_t list, uint8_t ref_idx, uint32_t b64_row_start, uint32_t b64_row_count,
+                         void *pred, uint32_t pred_stride); /* b64_row_count == 0: all rows from b64_row_start */
+
 /* Scan order of (tx_size, tx_type) as av1_scan_orders holds it (Codec/coefficients.h:2197); returns the length. */
 int svt_hip_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan);
 int svt_hip_tx_size_wide(int tx_size);

@@ -557,3 +557,51 @@ int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d) {
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Full-pel motion-compensated prediction from the ME results: for every 16x16 PU of every b64, copy the 16x16
+// block of the reference plane displaced by that PU's best full-pel MV (MeContext.p_sb_best_mv layout as written
+// by svt_hip_me_picture: [b64][list][ref][85], 16x16 PUs at n_idx 5..20 in quad-tree order).  Coordinates are
+// clamped into the picture (edge replication).  This is the integer-MV case of inter prediction -- the only part
+// of prediction this path needs to feed the RD kernels; sub-pel interpolation is out of scope.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+template <typename Pix> __global__ void fullpel_pred_kernel(const Pix *ref, uint32_t ref_stride, int width, int height, const uint32_t *sb_best_mv,
+                                                            int list, int ref_idx, uint32_t w64, int by16_first, Pix *pred, uint32_t pred_stride) {
+    const int bx16 = blockIdx.x, by16 = by16_first + (int)blockIdx.y; // 16x16 block coordinates
+    const int x0 = bx16 * 16, y0 = by16 * 16;
+    const uint32_t b = (uint32_t)(x0 >> 6) + (uint32_t)(y0 >> 6) * w64;
+    const int qx = (x0 >> 4) & 3, qy = (y0 >> 4) & 3;
+    const int z16 = (qx & 1) | ((qy & 1) << 1) | ((qx >> 1) << 2) | ((qy >> 1) << 3);
+    const uint32_t mv = sb_best_mv[((size_t)b * 8 + list * 4 + ref_idx) * 85 + 5 + z16];
+    const int mvx = (int16_t)(mv & 0xFFFF), mvy = (int16_t)(mv >> 16);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= width || y >= height) return;
+    int sx = x + mvx, sy = y + mvy;
+    sx = sx < 0 ? 0 : (sx > width - 1 ? width - 1 : sx);
+    sy = sy < 0 ? 0 : (sy > height - 1 ? height - 1 : sy);
+    pred[(size_t)y * pred_stride + x] = ref[(size_t)sy * ref_stride + sx];
+}
+} // namespace
+
+extern "C" int svt_hip_fullpel_pred(SvtHipContext *ctx, const void *ref, uint32_t ref_stride, uint32_t width, uint32_t height, uint8_t bit_depth,
+                                    const uint32_t *sb_best_mv, uint8_t list, uint8_t ref_idx, uint32_t b64_row_start, uint32_t b64_row_count, void *pred,
+                                    uint32_t pred_stride) {
+    if (!ctx || !ref || !sb_best_mv || !pred || list > 1 || ref_idx > 3 || (bit_depth != 8 && bit_depth != 10) || !width || !height)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "svt_hip_fullpel_pred: bad argument");
+    hipSetDevice(ctx->device);
+    const uint32_t w64 = (width + 63) / 64, h64 = (height + 63) / 64;
+    if (b64_row_start >= h64) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "svt_hip_fullpel_pred: b64_row_start %u >= %u", b64_row_start, h64);
+    if (b64_row_count == 0 || b64_row_start + b64_row_count > h64) b64_row_count = h64 - b64_row_start;
+    const uint32_t y_lo = b64_row_start * 64, y_hi = (b64_row_start + b64_row_count) * 64 < height ? (b64_row_start + b64_row_count) * 64 : height;
+    const dim3 g((width + 15) / 16, (y_hi - y_lo + 15) / 16), blk(256);
+    if (bit_depth == 8)
+        hipLaunchKernelGGL(fullpel_pred_kernel<uint8_t>, g, blk, 0, ctx->stream, static_cast<const uint8_t *>(ref), ref_stride, (int)width, (int)height,
+                           sb_best_mv, (int)list, (int)ref_idx, w64, (int)(y_lo / 16), static_cast<uint8_t *>(pred), pred_stride);
+    else
+        hipLaunchKernelGGL(fullpel_pred_kernel<uint16_t>, g, blk, 0, ctx->stream, static_cast<const uint16_t *>(ref), ref_stride, (int)width, (int)height,
+                           sb_best_mv, (int)list, (int)ref_idx, w64, (int)(y_lo / 16), static_cast<uint16_t *>(pred), pred_stride);
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
