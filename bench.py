@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-from svt_av1_psyex_amd import abi, api, rd, synth  # noqa: E402
+from svt_av1_psyex_amd import abi, api, rd, shard, synth  # noqa: E402
 
 W, H = 3840, 2160
 DISTS = (1, 2, 4, 8)
@@ -57,9 +57,7 @@ class Workload:
         self.pics = {i: ctx.upload(self.host8[i]) for i in range(N_FRAMES)}
         self.y10 = {i: torch.from_numpy(y10[i].astype(np.int16)).cuda().view(torch.int16) for i in (CUR,) + tuple(CUR - d for d in DISTS)}
         self.w64, self.h64 = (W + 63) // 64, (H + 63) // 64
-        # contiguous b64 row band of this rank
-        self.row0 = (self.h64 * rank) // world
-        self.row1 = (self.h64 * (rank + 1)) // world
+        self.row0, self.row1 = shard.band(self.h64, rank, world)  # contiguous b64 row band of this rank
         self.cfgs, self.descs = {}, {}
         for d in DISTS:
             self.cfgs[d] = api.config_from_preset(6, W, H, qp=35, temporal_layer_index=LAYER[d], hierarchical_levels=4)
@@ -68,25 +66,13 @@ class Workload:
             self.descs[d] = desc
         self.n_pu = abi.n_pu(desc.enable_me_16x16, desc.enable_me_8x8)
         # ME results of the 4 pictures of a step: ONE compact device buffer holding only this rank's b64 rows (padded to
-        # the largest band so every rank contributes the same byte count to the all-gather).  The kernel indexes its
-        # outputs by absolute b64 index, so each field pointer is biased back by the band's first row.
-        rows_max = -(-self.h64 // world)
-        nbb = rows_max * self.w64
-        self.me_fields = [(n, dt, c(self.n_pu, desc.max_refs, desc.max_cand)) for n, dt, c in abi.RESULT_FIELDS if n not in ("hme_sc", "hme_sad", "do_ref")]
-        self.me_bytes_per_b64 = sum(np.dtype(dt).itemsize * c for _, dt, c in self.me_fields)
-        self.me_buf = torch.zeros(len(DISTS) * nbb * self.me_bytes_per_b64, dtype=torch.uint8, device="cuda")
+        # the largest band so that every rank contributes the same byte count to the all-gather): shard.BandLayout.
+        self.layout = shard.BandLayout(self.w64, self.h64, world, self.n_pu, desc.max_refs, desc.max_cand, n_pictures=len(DISTS))
+        self.me_buf = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device="cuda")
         self.me_res, self.mv_ptr = {}, {}
-        off = 0
-        first = self.row0 * self.w64
-        for d in DISTS:
-            res = abi.MeResults()
-            for name, dt, c in self.me_fields:
-                per = np.dtype(dt).itemsize * c
-                setattr(res, name, self.me_buf.data_ptr() + off - first * per)
-                if name == "sb_best_mv":
-                    self.mv_ptr[d] = self.me_buf.data_ptr() + off - first * per
-                off += nbb * per
-            self.me_res[d] = res
+        for pi, d in enumerate(DISTS):
+            self.me_res[d] = self.layout.results_struct(self.me_buf.data_ptr(), pi, rank)
+            self.mv_ptr[d] = self.me_res[d].sb_best_mv
         # RD: prediction / recon planes and job lists restricted to this rank's rows
         self.pred = torch.zeros(H * W, dtype=torch.int16, device="cuda")
         self.recon = torch.zeros(H * W, dtype=torch.int16, device="cuda")

@@ -25,7 +25,7 @@ namespace {
 
 constexpr int kThreads  = SVT_HIP_ME_THREADS;
 constexpr int kMaxReq   = 32;    // searches per batch (4 HME regions x 8 refs)
-constexpr int kWinBytes = 32768; // LDS window arena
+constexpr int kWinBytes = 16384; // LDS window arena (4 workgroups per CU fit the 160 KiB LDS)
 constexpr int kNarrowMaxPos = 32; // searches with at most this many positions are split by block row instead
 
 // z_to_raster, motion_estimation.c:2520-2531: n_idx (quad-tree order) -> raster-within-depth PU index
@@ -109,6 +109,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
 };
 
 struct Shared {
+    MeKernelParams params; // launch parameters, copied once per workgroup (uniform LDS reads afterwards)
     St      st;
     uint8_t src64[64 * 64];
     uint8_t src32[32 * 32];
@@ -587,11 +588,16 @@ __device__ __forceinline__ void push_zz_req(St &st, const DevPlane &rp, int dx, 
 // =================================================================================================
 // The kernel
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS)
-svt_hip_me_b64_kernel(const MeKernelParams p) {
+extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS, 4)
+svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &sh = *reinterpret_cast<Shared *>(smem_raw);
     St     &st = sh.st;
+    static_assert(sizeof(MeKernelParams) % 4 == 0, "params are copied as dwords");
+    for (int i = threadIdx.x; i < (int)(sizeof(MeKernelParams) / 4); i += kThreads)
+        reinterpret_cast<uint32_t *>(&sh.params)[i] = reinterpret_cast<const uint32_t *>(gparams)[i];
+    __syncthreads();
+    const MeKernelParams &p = sh.params;
     const SvtHipMeConfig      &c = p.cfg;
     const SvtHipMePictureDesc &d = p.desc;
     const int tid      = threadIdx.x;
@@ -1281,9 +1287,11 @@ int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, uint32_t
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    uint32_t grid = (uint32_t)ctx->num_cus * 2u;
+    uint32_t grid = (uint32_t)ctx->num_cus * 4u; // 4 workgroups per CU: <= 128 VGPRs (launch bounds) and <= 40 KiB LDS each
     if (grid > n_jobs) grid = n_jobs;
-    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, ctx->stream, *params);
+    // parameter block -> HBM (stream ordered: the previous launch has consumed the buffer before this copy lands)
+    SVT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->me_params, params, sizeof(MeKernelParams), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, ctx->stream, static_cast<const MeKernelParams *>(ctx->me_params));
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }

@@ -118,7 +118,8 @@ int svt_hip_context_create(SvtHipContext **out, int device) {
     ctx->device  = device;
     ctx->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->queue_head), SVT_HIP_ME_QUEUES * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&ctx->queue_head), SVT_HIP_ME_QUEUES * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&ctx->me_params, sizeof(MeKernelParams)) != hipSuccess) {
         free(ctx);
         return SVT_HIP_ERR_NO_DEVICE;
     }
@@ -132,6 +133,7 @@ void svt_hip_context_destroy(SvtHipContext *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     hipFree(ctx->queue_head);
+    hipFree(ctx->me_params);
     hipStreamDestroy(ctx->stream);
     free(ctx);
 }

@@ -11,6 +11,7 @@ struct SvtHipContext {
     int         num_cus;
     hipStream_t stream;
     uint32_t   *queue_head; // SVT_HIP_ME_QUEUES counters in HBM
+    void       *me_params;  // device copy of the ME kernel's MeKernelParams
     // scratch result buffers of the synchronous (host-pointer) entry points, grown on demand
     void  *scratch;
     size_t scratch_bytes;

@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the row-band sharding + all-gather of per-b64 ME results reproduces the single-rank
+results.  The compute stand-in on CPU is the oracle; on GPUs bench.py runs the same layout code over RCCL."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from me_cases import MeCase, compare
+from svt_av1_psyex_amd import abi, shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import pyoracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = MeCase(640, 360, enc_mode=6, seed=9)
+        d = case.desc
+        w64, h64 = 10, 6
+        lay = shard.BandLayout(w64, h64, world, abi.n_pu(d.enable_me_16x16, d.enable_me_8x8), d.max_refs, d.max_cand, n_pictures=2)
+        buf = np.zeros(lay.nbytes, np.uint8)
+        r0, r1 = shard.band(h64, rank, world)
+        for pic in range(2):  # two pictures in one exchange, as bench.py does with four
+            d.b64_row_start, d.b64_row_count = r0, r1 - r0
+            res = lay.results_struct(buf.ctypes.data, pic, rank)
+            rc = pyoracle.load_oracle().orc_me_picture(C.byref(case.cfg), C.byref(d), case.cur.descs(), pyoracle.ref_plane_array(case.refs), C.byref(res))
+            assert rc == 0
+        mine = torch.from_numpy(buf)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        if rank == 0:
+            q.put(np.stack([g.numpy() for g in gathered]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_sharding_and_all_gather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case = MeCase(640, 360, enc_mode=6, seed=9)
+    whole = case.run_cpu("oracle")
+    d = case.desc
+    lay = shard.BandLayout(10, 6, world, abi.n_pu(d.enable_me_16x16, d.enable_me_8x8), d.max_refs, d.max_cand, n_pictures=2)
+    for pic in range(2):
+        merged = lay.unpack(gathered, pic)
+        assert not compare({k: whole[k] for k in merged}, merged)
+
+
+def test_bands_cover_every_row_once():
+    for h64 in (5, 17, 34):
+        for world in (1, 2, 3, 4, 8):
+            rows = [r for k in range(world) for r in range(*shard.band(h64, k, world))]
+            assert rows == list(range(h64))
+            assert shard.rows_max(h64, world) * world >= h64
