@@ -21,6 +21,23 @@
 #include <stdint.h>
 #include "me_kernel.h"
 
+// Diagnostic build only (-DSVT_HIP_ME_PROFILE): lane 0 accumulates shader-clock deltas per phase (private array) and adds
+// them to queue_head[16 + 2*i] (u64) when the workgroup retires.  Never defined in the shipped library.
+#ifdef SVT_HIP_ME_PROFILE
+struct Prof { unsigned long long acc[24], last; };
+#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < 24; i_++) prof_.acc[i_] = 0; prof_.last = clock64(); Prof *prof = &prof_
+#define PROF(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); prof->acc[i] += t_ - prof->last; prof->last = t_; } } while (0)
+#define PROF_FLUSH(ptr) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 24; i_++) atomicAdd((unsigned long long *)(ptr) + i_, prof->acc[i_]); } while (0)
+#define PROF_PARAM , Prof *prof
+#define PROF_ARG , prof
+#else
+#define PROF_DECL do { } while (0)
+#define PROF(i) do { } while (0)
+#define PROF_FLUSH(ptr) do { } while (0)
+#define PROF_PARAM
+#define PROF_ARG
+#endif
+
 namespace {
 
 constexpr int kThreads  = SVT_HIP_ME_THREADS;
@@ -58,6 +75,7 @@ struct Tile { // a rectangle of a Req whose window fits the LDS arena
     uint32_t lds_off;      // byte offset in the arena
     uint32_t rows;         // window rows staged
     uint32_t item0, nitems, ng;
+    uint32_t vec0;         // index of this tile's first 16-byte vector in the batch's flattened staging order
 };
 
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
@@ -93,7 +111,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     uint8_t  lvl_req[2][4][2][2];
     uint8_t  c00_req[2][4];
     // batch machinery
-    int      nreq, ntile, next_req, next_x, next_y, nitems, cur_tw, cur_th;
+    int      nreq, ntile, next_req, next_x, next_y, nitems, nvec, cur_tw, cur_th;
     Req      req[kMaxReq];
     u64      req_key[kMaxReq];
     Tile     tile[kMaxReq];
@@ -154,7 +172,7 @@ __device__ __forceinline__ uint32_t tile_bytes(const Req &r, int shift, int w, i
 // lane 0: cut the pending requests into tiles whose reference windows fit the LDS arena.  Every request is
 // cut on a fixed (cur_tw x cur_th) grid chosen so that any of its tiles fits an empty arena.
 __device__ void plan_tiles(St &st) {
-    uint32_t used = 0, items = 0;
+    uint32_t used = 0, items = 0, vecs = 0;
     int      nt = 0;
     while (st.next_req < st.nreq && nt < kMaxReq) {
         const Req &r = st.req[st.next_req];
@@ -184,6 +202,8 @@ __device__ void plan_tiles(St &st) {
         t.narrow  = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
         t.item0   = items;
         t.nitems  = t.ng * (uint32_t)h * (t.narrow ? r.bh : 1u);
+        t.vec0    = vecs;
+        vecs += (uint32_t)(t.pitch >> 4) * t.rows;
         items += t.nitems;
         used += need;
         nt++;
@@ -199,22 +219,92 @@ __device__ void plan_tiles(St &st) {
     }
     st.ntile  = nt;
     st.nitems = (int)items;
+    st.nvec   = (int)vecs;
 }
 
-// all threads: copy the tiles' reference windows into the LDS arena with aligned 16-byte loads
+// wave 0: plan the next round in parallel -- lane i sizes pending request i as ONE tile; an inclusive scan of the byte
+// counts gives the arena offsets and how many leading requests fit.  Returns false (nothing planned) when the cursor is
+// inside a request or the first pending request does not fit the arena in one piece: lane 0 then runs plan_tiles().
+__device__ __forceinline__ bool plan_tiles_wave(St &st) {
+    const int lane = threadIdx.x;
+    if (st.next_x != 0 || st.next_y != 0) return false;
+    const int  idx  = st.next_req + lane;
+    const bool live = lane < kMaxReq && idx < st.nreq;
+    uint32_t need = 0, items = 0, vecs = 0, pitch = 0, rows = 0, ng = 0;
+    int      shift = 0, narrow = 0;
+    if (live) {
+        const Req &r = st.req[idx];
+        shift  = (int)((uintptr_t)r.win & 15);
+        pitch  = (uint32_t)(((shift + r.sa_w - 1 + r.bw + 15) & ~15) + 16);
+        rows   = (uint32_t)(r.sa_h - 1 + (r.bh - 1) * r.rs + 1);
+        need   = pitch * rows;
+        ng     = (uint32_t)((shift & 3) + r.sa_w + 3) >> 2;
+        narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
+        items  = ng * (uint32_t)r.sa_h * (narrow ? r.bh : 1u);
+        vecs   = (pitch >> 4) * rows;
+    }
+    uint32_t pb = need, pi = items, pv = vecs; // inclusive scans
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t tb = __shfl_up(pb, o, 64), ti = __shfl_up(pi, o, 64), tv = __shfl_up(pv, o, 64);
+        if (lane >= o) { pb += tb; pi += ti; pv += tv; }
+    }
+    const bool ok    = live && pb <= (uint32_t)kWinBytes;
+    const u64  mask  = __ballot(ok);
+    const int  count = mask == ~0ull ? 64 : __builtin_ctzll(~mask); // leading requests that fit
+    if (count == 0) return false;
+    if (lane < count) {
+        const Req &r = st.req[idx];
+        Tile &t   = st.tile[lane];
+        t.req     = (uint8_t)idx;
+        t.narrow  = (uint8_t)narrow;
+        t.x0 = 0; t.y0 = 0;
+        t.w       = r.sa_w;
+        t.h       = r.sa_h;
+        t.pitch   = (uint16_t)pitch;
+        t.shift   = (uint16_t)shift;
+        t.lds_off = pb - need;
+        t.rows    = rows;
+        t.item0   = pi - items;
+        t.nitems  = items;
+        t.ng      = ng;
+        t.vec0    = pv - vecs;
+    }
+    if (lane == count - 1) {
+        st.ntile    = count;
+        st.nitems   = (int)pi;
+        st.nvec     = (int)pv;
+        st.next_req = idx + 1;
+    }
+    return true;
+}
+
+// all threads: copy the tiles' reference windows into the LDS arena with aligned 16-byte loads; the (tile, row, vector)
+// space is flattened so that every thread keeps four independent loads in flight
 __device__ __forceinline__ void stage_tiles(Shared &sh) {
     const St &st = sh.st;
-    for (int ti = 0; ti < st.ntile; ti++) {
-        const Tile &t = st.tile[ti];
-        const Req  &r = st.req[t.req];
-        const uint8_t *g0 = r.win + t.x0 + (long long)t.y0 * r.stride - t.shift; // 16-byte aligned
-        const int vec_per_row = t.pitch >> 4;
-        const int total       = vec_per_row * (int)t.rows;
-        for (int i = threadIdx.x; i < total; i += kThreads) {
-            const int row = i / vec_per_row, c = i - row * vec_per_row;
-            const uint4 v = *reinterpret_cast<const uint4 *>(g0 + (long long)row * r.stride + c * 16);
-            *reinterpret_cast<uint4 *>(&sh.win[t.lds_off + row * t.pitch + c * 16]) = v;
+    const int nvec = st.nvec;
+    for (int base = threadIdx.x; base < nvec; base += 4 * kThreads) {
+        uint4 v[4];
+        int   dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * kThreads;
+            dst[u] = -1;
+            if (i < nvec) {
+                int ti = 0;
+                while (ti + 1 < st.ntile && i >= (int)st.tile[ti + 1].vec0) ti++;
+                const Tile &t = st.tile[ti];
+                const Req  &r = st.req[t.req];
+                const int k = i - (int)t.vec0, vpr = t.pitch >> 4, row = k / vpr, c = k - row * vpr;
+                const uint8_t *g0 = r.win + t.x0 + (long long)t.y0 * r.stride - t.shift; // 16-byte aligned
+                v[u]   = *reinterpret_cast<const uint4 *>(g0 + (long long)row * r.stride + c * 16);
+                dst[u] = (int)t.lds_off + row * t.pitch + c * 16;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (dst[u] >= 0) *reinterpret_cast<uint4 *>(&sh.win[dst[u]]) = v[u];
     }
 }
 
@@ -222,35 +312,61 @@ __device__ __forceinline__ const uint8_t *src_view(const Shared &sh, int level) 
     return level == 2 ? sh.src64 : (level == 1 ? sh.src32 : sh.src16);
 }
 
-// Packed SAD of 4 neighbouring positions over block rows [r0, r1): returns 4 x u32 sums via out[].
-// The block's source rows come from LDS (broadcast reads); the reference rows from the staged window.
+// Packed SAD of 4 neighbouring positions over block rows [r0, r1): 4 x u32 sums in out[].  The block's source rows
+// come from LDS (same address in every lane: broadcast reads), the reference rows from the staged window.  NDW = block
+// width in dwords; a whole row is fetched before its qsads issue so the LDS reads overlap instead of serialising.
+template <int NDW>
+__device__ __forceinline__ void quad_sad_rows(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int r0, int r1,
+                                              uint32_t out[4]) {
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    constexpr int kRowsPerFlush = 64 / NDW; // 64 qsads x 4 x 255 < 65536: the packed 16-bit lanes cannot overflow before a flush
+    for (int rb = r0; rb < r1; rb += kRowsPerFlush) {
+        const int re = rb + kRowsPerFlush < r1 ? rb + kRowsPerFlush : r1;
+        u64       acc = 0;
+        for (int r = rb; r < re; r++) {
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * rs * src_pitch);
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
+            uint32_t sv[NDW], wv[NDW + 1];
+#pragma unroll
+            for (int j = 0; j < NDW; j++) sv[j] = s[j];
+#pragma unroll
+            for (int j = 0; j <= NDW; j++) wv[j] = w[j];
+#pragma unroll
+            for (int j = 0; j < NDW; j++) acc = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 1] << 32) | wv[j], sv[j], acc);
+        }
+        a0 += (uint32_t)(acc & 0xFFFF); a1 += (uint32_t)((acc >> 16) & 0xFFFF);
+        a2 += (uint32_t)((acc >> 32) & 0xFFFF); a3 += (uint32_t)(acc >> 48);
+    }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+}
+
 __device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0,
                                          int r1, uint32_t out[4]) {
+    switch (bw) { // wave-uniform for all practical batches (one block width per HME level)
+    case 16: quad_sad_rows<4>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 32: quad_sad_rows<8>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 64: quad_sad_rows<16>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 8: quad_sad_rows<2>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 4: quad_sad_rows<1>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    default: break;
+    }
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const int nd = bw >> 2;
-    if ((bw & 3) == 0) {
-        u64 acc = 0;
-        int cnt = 0;
+    if ((bw & 3) == 0) { // other multiples of 4 (right-edge blocks): generic dword loop
+        const int nd = bw >> 2;
         for (int r = r0; r < r1; r++) {
             const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * rs * src_pitch);
             const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
-            uint32_t lo = w[0];
+            u64      acc = 0; // at most 16 qsads per row: no overflow within a row
+            uint32_t lo  = w[0];
             for (int j = 0; j < nd; j++) {
                 const uint32_t hi = w[j + 1];
                 acc = __builtin_amdgcn_qsad_pk_u16_u8(((u64)hi << 32) | lo, s[j], acc);
                 lo  = hi;
             }
-            cnt += nd;
-            if (cnt + nd > 64) { // 64 x 4 x 255 < 65536: flush the packed 16-bit lanes
-                a0 += (uint32_t)(acc & 0xFFFF); a1 += (uint32_t)((acc >> 16) & 0xFFFF);
-                a2 += (uint32_t)((acc >> 32) & 0xFFFF); a3 += (uint32_t)(acc >> 48);
-                acc = 0; cnt = 0;
-            }
+            a0 += (uint32_t)(acc & 0xFFFF); a1 += (uint32_t)((acc >> 16) & 0xFFFF);
+            a2 += (uint32_t)((acc >> 32) & 0xFFFF); a3 += (uint32_t)(acc >> 48);
         }
-        a0 += (uint32_t)(acc & 0xFFFF); a1 += (uint32_t)((acc >> 16) & 0xFFFF);
-        a2 += (uint32_t)((acc >> 32) & 0xFFFF); a3 += (uint32_t)(acc >> 48);
-    } else {
-        // widths that are not a multiple of 4 (right-edge blocks of odd picture widths): byte loop
+    } else { // widths that are not a multiple of 4 (right-edge blocks of odd picture widths): byte loop
         for (int r = r0; r < r1; r++) {
             const uint8_t *s = src + r * rs * src_pitch;
             const uint8_t *w = wrow0 + r * rs * pitch;
@@ -338,7 +454,7 @@ __device__ __forceinline__ void eval_tiles(Shared &sh) {
 
 // all threads: run st.req[0 .. nreq) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x),
 // or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.
-__device__ __forceinline__ void run_searches(Shared &sh) {
+__device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
     St &st = sh.st;
     if (threadIdx.x == 0) {
         st.next_req = 0; st.next_x = 0; st.next_y = 0;
@@ -346,12 +462,19 @@ __device__ __forceinline__ void run_searches(Shared &sh) {
     }
     __syncthreads();
     for (;;) {
-        if (threadIdx.x == 0) plan_tiles(st);
+        PROF(23);
+        if (threadIdx.x < 64) { // wave 0 plans; the serial planner only handles requests that must be cut into tiles
+            const bool planned = plan_tiles_wave(st);
+            if (!planned && threadIdx.x == 0) plan_tiles(st);
+        }
         __syncthreads();
+        PROF(17);
         if (st.ntile == 0) break; // uniform: read from LDS after the barrier
         stage_tiles(sh);
         __syncthreads();
+        PROF(18);
         eval_tiles(sh);
+        PROF(19);
     }
     __syncthreads();
 }
@@ -609,6 +732,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7;
     int queue_probe = 0; // only lane 0's copy is used
+    PROF_DECL;
 
     for (;;) {
         // ---- fetch the next b64 job -----------------------------------------------------------------
@@ -628,6 +752,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
         __syncthreads();
         const int job = st.job;
         if (job < 0) break; // every wave of the workgroup takes this exit together
+        PROF(0);
         const uint32_t bxi = (uint32_t)job % p.w64, byi = p.row0 + (uint32_t)job / p.w64;
         const uint32_t b   = bxi + byi * p.w64;
 
@@ -671,6 +796,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
         }
         __syncthreads();
 
+        PROF(1);
         // ---- init_zz_sad (motion_estimation.c:2382-2437) ------------------------------------------------
         if (c.me_early_exit_th || c.me_safe_limit_zz_th) {
             if (tid == 0) {
@@ -680,7 +806,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                         if (searched(p, li)) push_zz_req(st, p.ref[li][ri].lvl[2], 0, 0);
             }
             __syncthreads();
-            run_searches(sh);
+            run_searches(sh PROF_ARG);
             if (tid == 0) {
                 uint32_t best = 0xFFFFFFFFu;
                 int      k    = 0;
@@ -707,6 +833,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             __syncthreads();
         }
 
+        PROF(2);
         // ---- prehme_b64 (motion_estimation.c:1693-1796) ---------------------------------------------------
         if (c.prehme_enable) {
             // with l1_early_exit, list 1 looks at list 0's results: one batch per list then
@@ -747,7 +874,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                         }
                 }
                 __syncthreads();
-                run_searches(sh);
+                run_searches(sh PROF_ARG);
                 if (tid == 0) {
                     for (int li = l_lo; li < l_hi; li++)
                         for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
@@ -791,6 +918,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             __syncthreads();
         }
 
+        PROF(3);
         if (c.enable_hme_flag) {
             // ---- hme_level0_b64 (motion_estimation.c:1906-2036) ------------------------------------------
             if (c.enable_hme_level0_flag) {
@@ -828,7 +956,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             }
                     }
                     __syncthreads();
-                    run_searches(sh);
+                    run_searches(sh PROF_ARG);
                     if (tid == 0) {
                         for (int li = 0; li < nl; li++)
                             for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
@@ -863,6 +991,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                     __syncthreads();
                 }
             }
+            PROF(4);
             // ---- hme_level1_b64 / hme_level2_b64 (motion_estimation.c:2041-2177) ----------------------------
             for (int lvl = 1; lvl <= 2; lvl++) {
                 if (lvl == 1 ? !c.enable_hme_level1_flag : !c.enable_hme_level2_flag) continue;
@@ -900,7 +1029,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                         }
                 }
                 __syncthreads();
-                run_searches(sh);
+                run_searches(sh PROF_ARG);
                 if (tid == 0) {
                     const int scale = (lvl == 1) ? 2 : 1;
                     for (int li = 0; li < nl; li++)
@@ -920,6 +1049,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             }
         }
 
+        PROF(5);
         // ---- set_final_seach_centre_sb (:2182-2380), hme_prune_ref_and_adjust_sr (:2477-2518) -------------
         if (tid == 0) {
             {
@@ -970,6 +1100,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
         }
         __syncthreads();
 
+        PROF(6);
         // ---- integer_search_b64 (motion_estimation.c:1249-1516) --------------------------------------------
         // Refs are independent except through p_sb_best_sad[0][0][0] when enable_me_sr_adjustment == 2 (and the
         // zz early exit is off); then list0/ref0 is finished first.  Per group: (a) check_00_center SADs,
@@ -1002,7 +1133,9 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                         }
                 }
                 __syncthreads();
-                if (st.nreq) run_searches(sh); // uniform (LDS value read after the barrier)
+                PROF(7);
+                if (st.nreq) run_searches(sh PROF_ARG); // uniform (LDS value read after the barrier)
+                PROF(8);
                 if (tid == 0) {
                     st.nme = 0; st.nprobe = 0;
                     for (int li = 0; li < nl; li++)
@@ -1049,7 +1182,9 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                         }
                 }
                 __syncthreads();
+                PROF(9);
                 if (st.nprobe) run_me_searches(sh, p, st.me_probe, st.nprobe); // uniform
+                PROF(10);
                 if (tid == 0) {
                     const int pic_w = (int16_t)d.aligned_width, pic_h = (int16_t)d.aligned_height;
                     for (int i = 0; i < st.nme; i++) {
@@ -1074,7 +1209,9 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                     }
                 }
                 __syncthreads();
+                PROF(11);
                 run_me_searches(sh, p, st.me, st.nme);
+                PROF(12);
             }
         }
 
@@ -1099,6 +1236,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             __syncthreads();
         }
 
+        PROF(13);
         // ---- construct_me_candidate_array* (motion_estimation.c:2532-2836), one thread per PU ----------------
         {
             const uint32_t n_pu = p.n_pu;
@@ -1196,6 +1334,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             }
             __syncthreads();
 
+            PROF(14);
             // ---- compute_distortion (:2964-3008) + perform_gm_detection (:2838-2961) ---------------------------
             if (tid == 0) {
                 uint32_t d32 = 0, d16 = 0, d8 = 0;
@@ -1248,6 +1387,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                 p.res.stationary_block_present_sb[b] = stationary;
                 p.res.rc_me_allow_gm[b]              = allow_gm;
             }
+            PROF(15);
             // ---- optional search-level results ------------------------------------------------------------------
             if (p.res.sb_best_sad || p.res.sb_best_mv)
                 for (int i = tid; i < 2 * 4 * 85; i += kThreads) {
@@ -1268,7 +1408,9 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             }
         }
         __syncthreads();
+        PROF(16);
     }
+    PROF_FLUSH(p.queue_head + 16);
 }
 
 size_t svt_hip_me_kernel_lds_bytes(void) { return sizeof(Shared); }

@@ -118,7 +118,7 @@ int svt_hip_context_create(SvtHipContext **out, int device) {
     ctx->device  = device;
     ctx->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->queue_head), SVT_HIP_ME_QUEUES * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->queue_head), 512) != hipSuccess || hipMemset(ctx->queue_head, 0, 512) != hipSuccess ||
         hipMalloc(&ctx->me_params, sizeof(MeKernelParams)) != hipSuccess) {
         free(ctx);
         return SVT_HIP_ERR_NO_DEVICE;
@@ -203,5 +203,14 @@ int svt_hip_scratch(SvtHipContext *ctx, size_t bytes, void **out) {
         ctx->scratch_bytes = bytes;
     }
     *out = ctx->scratch;
+    return SVT_HIP_OK;
+}
+
+// Diagnostic: per-phase shader-clock sums of the ME kernel (non-zero only in a -DSVT_HIP_ME_PROFILE build); clears them.
+extern "C" int svt_hip_me_profile_read(SvtHipContext *ctx, unsigned long long out[24]) {
+    if (!ctx || !out) return SVT_HIP_ERR_BAD_PARAM;
+    SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SVT_HIP_CHECK(ctx, hipMemcpy(out, reinterpret_cast<char *>(ctx->queue_head) + 64, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    SVT_HIP_CHECK(ctx, hipMemset(reinterpret_cast<char *>(ctx->queue_head) + 64, 0, 24 * sizeof(unsigned long long)));
     return SVT_HIP_OK;
 }
