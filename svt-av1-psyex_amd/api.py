@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvthip.so")
+LIB_PATH = os.environ.get("SVT_HIP_LIBRARY") or os.path.join(_HERE, "libsvthip.so")  # override: a tuning build of the same ABI
 _lib = None
 
 ERRORS = {1: "no usable gfx950 device", 2: "bad parameter", 3: "out of device memory", 4: "launch/stream error"}

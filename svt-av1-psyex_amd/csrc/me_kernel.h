@@ -4,7 +4,17 @@
 #include <stdint.h>
 #include "../../include/svt_hip_me.h"
 
+// Workgroup shape of the ME kernel (tunable at build time): threads per 64x64 block, resident workgroups per CU the
+// grid and the launch bounds are sized for, and the LDS window arena each workgroup owns.
+#ifndef SVT_HIP_ME_THREADS
 #define SVT_HIP_ME_THREADS 256
+#endif
+#ifndef SVT_HIP_ME_WG_PER_CU
+#define SVT_HIP_ME_WG_PER_CU 4
+#endif
+#ifndef SVT_HIP_ME_WIN_BYTES
+#define SVT_HIP_ME_WIN_BYTES 16384
+#endif
 #define SVT_HIP_ME_QUEUES 8 /* one b64 band queue per XCD */
 
 // A padded 8-bit luma plane resident in HBM.  `base` is the padded buffer's first byte (buffer_y); it and

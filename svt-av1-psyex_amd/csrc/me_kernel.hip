@@ -41,8 +41,9 @@ struct Prof { unsigned long long acc[24], last; };
 namespace {
 
 constexpr int kThreads  = SVT_HIP_ME_THREADS;
+constexpr int kWaves    = kThreads / 64;
 constexpr int kMaxReq   = 32;    // searches per batch (4 HME regions x 8 refs)
-constexpr int kWinBytes = 16384; // LDS window arena (4 workgroups per CU fit the 160 KiB LDS)
+constexpr int kWinBytes = SVT_HIP_ME_WIN_BYTES; // LDS window arena
 constexpr int kNarrowMaxPos = 32; // searches with at most this many positions are split by block row instead
 
 // z_to_raster, motion_estimation.c:2520-2531: n_idx (quad-tree order) -> raster-within-depth PU index
@@ -118,7 +119,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     uint32_t sadbuf[kMaxReq * kNarrowMaxPos];
     int      nme, nprobe;
     MeReq    me[8], me_probe[8];
-    u64      wave_best[4][85];
+    u64      wave_best[kWaves][85];
     uint32_t best_sad[2][4][85];
     uint32_t best_mv[2][4][85];
     uint32_t me_dist[85];
@@ -383,7 +384,7 @@ __device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, cons
 __device__ __forceinline__ void lds_min_u64(u64 *addr, u64 v) { atomicMin(addr, v); }
 
 // all threads: evaluate every tile of the current plan
-__device__ __forceinline__ void eval_tiles(Shared &sh) {
+__device__ __forceinline__ void eval_tiles(Shared &sh PROF_PARAM) {
     St &st = sh.st;
     // zero the narrow accumulators
     for (int ti = 0; ti < st.ntile; ti++) {
@@ -392,6 +393,7 @@ __device__ __forceinline__ void eval_tiles(Shared &sh) {
             for (int i = threadIdx.x; i < t.w * t.h; i += kThreads) st.sadbuf[ti * kNarrowMaxPos + i] = 0;
     }
     __syncthreads();
+    PROF(20);
     int ti = 0, cur_req = -1;
     u64 cur_best = ~0ull;
     for (int it = threadIdx.x; it < st.nitems; it += kThreads) {
@@ -437,7 +439,9 @@ __device__ __forceinline__ void eval_tiles(Shared &sh) {
         }
     }
     if (cur_best != ~0ull) lds_min_u64(&st.req_key[cur_req], cur_best);
+    PROF(21);
     __syncthreads();
+    PROF(22);
     for (int tj = 0; tj < st.ntile; tj++) {
         const Tile &t = st.tile[tj];
         if (!t.narrow) continue;
@@ -473,7 +477,7 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
         stage_tiles(sh);
         __syncthreads();
         PROF(18);
-        eval_tiles(sh);
+        eval_tiles(sh PROF_ARG);
         PROF(19);
     }
     __syncthreads();
@@ -577,7 +581,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, const MeKernelParams
                 }
                 __syncthreads();
                 const int ng = ((shift & 3) + w + 3) >> 2;
-                for (int q = wave; q < ng * h; q += 4) {
+                for (int q = wave; q < ng * h; q += kWaves) {
                     const int y = q / ng, g = q - y * ng;
                     const int col0 = (shift & ~3) + 4 * g, xq = col0 - shift;
                     const uint8_t *wp = &sh.win[(y + by * 8) * pitch + col0 + bx * 8];
@@ -612,10 +616,9 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, const MeKernelParams
         if ((lane & 15) == 0) st.wave_best[wave][1 + (lane >> 4)] = b32;
         if (lane == 0) st.wave_best[wave][0] = b64;
         __syncthreads();
-        if (threadIdx.x < 85) {
-            const int n = threadIdx.x;
+        for (int n = threadIdx.x; n < 85; n += kThreads) {
             u64 k = st.wave_best[0][n];
-            for (int wv = 1; wv < 4; wv++) k = st.wave_best[wv][n] < k ? st.wave_best[wv][n] : k;
+            for (int wv = 1; wv < kWaves; wv++) k = st.wave_best[wv][n] < k ? st.wave_best[wv][n] : k;
             const uint32_t sad = (uint32_t)(k >> 32);
             if (k != ~0ull && sad < st.best_sad[m.li][m.ri][n]) {
                 const uint32_t ord = (uint32_t)k;
@@ -711,7 +714,7 @@ __device__ __forceinline__ void push_zz_req(St &st, const DevPlane &rp, int dx, 
 // =================================================================================================
 // The kernel
 // =================================================================================================
-extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS, 4)
+extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS, (SVT_HIP_ME_WG_PER_CU * (SVT_HIP_ME_THREADS / 64) + 3) / 4)
 svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &sh = *reinterpret_cast<Shared *>(smem_raw);
@@ -797,16 +800,19 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
         __syncthreads();
 
         PROF(1);
+        // The stages below run as one loop around a SINGLE inlined copy of run_searches / run_me_searches (the kernel
+        // must stay small enough for the instruction cache shared by two CUs): each stage has a lane-0 "pre" part that
+        // pushes its searches and a lane-0 "post" part that folds the results into the block state.
         // ---- init_zz_sad (motion_estimation.c:2382-2437) ------------------------------------------------
-        if (c.me_early_exit_th || c.me_safe_limit_zz_th) {
+        auto zz_pre = [&]() {
             if (tid == 0) {
                 st.nreq = 0;
                 for (int li = 0; li < nl; li++)
                     for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
                         if (searched(p, li)) push_zz_req(st, p.ref[li][ri].lvl[2], 0, 0);
             }
-            __syncthreads();
-            run_searches(sh PROF_ARG);
+        };
+        auto zz_post = [&]() {
             if (tid == 0) {
                 uint32_t best = 0xFFFFFFFFu;
                 int      k    = 0;
@@ -830,68 +836,64 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             for (int ri = 1; ri < d.num_of_ref_pic_to_search[li]; ri++) st.do_ref[li][ri] = 0;
                 }
             }
-            __syncthreads();
-        }
-
-        PROF(2);
+        };
         // ---- prehme_b64 (motion_estimation.c:1693-1796) ---------------------------------------------------
-        if (c.prehme_enable) {
-            // with l1_early_exit, list 1 looks at list 0's results: one batch per list then
-            const int nbatch = c.prehme_l1_early_exit ? nl : 1;
-            for (int bi = 0; bi < nbatch; bi++) {
-                const int l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
-                if (tid == 0) {
-                    st.nreq = 0;
-                    for (int li = l_lo; li < l_hi; li++)
-                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                            st.ph_req[li][ri][0] = st.ph_req[li][ri][1] = 0;
-                            if (!searched(p, li)) continue;
-                            const uint32_t f = scaled_distance(ref_distance(p, li, ri));
-                            for (int sri = 0; sri < 2; sri++) {
-                                PreHme &ph = st.prehme[li][ri][sri];
-                                // check_prehme_early_exit (:1693-1720)
-                                if (c.me_early_exit_th && st.zz_sad[li][ri] < c.me_early_exit_th) { ph.col = ph.row = 0; ph.sad = 0; ph.valid = 1; continue; }
-                                if (c.prehme_l1_early_exit) {
-                                    const PreHme &q = st.prehme[0][ri][sri];
-                                    if (li == 1 && q.valid && (q.sad < 32 * 32 || (iabs(q.col) < 16 && iabs(q.row) < 16))) {
-                                        ph.col = (int16_t)-q.col; ph.row = (int16_t)-q.row; ph.sad = q.sad; ph.valid = 1; continue;
-                                    }
+        // with l1_early_exit, list 1 looks at list 0's results: one batch per list then
+        auto prehme_pre = [&](int bi) {
+            const int l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
+            if (tid == 0) {
+                st.nreq = 0;
+                for (int li = l_lo; li < l_hi; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        st.ph_req[li][ri][0] = st.ph_req[li][ri][1] = 0;
+                        if (!searched(p, li)) continue;
+                        const uint32_t f = scaled_distance(ref_distance(p, li, ri));
+                        for (int sri = 0; sri < 2; sri++) {
+                            PreHme &ph = st.prehme[li][ri][sri];
+                            // check_prehme_early_exit (:1693-1720)
+                            if (c.me_early_exit_th && st.zz_sad[li][ri] < c.me_early_exit_th) { ph.col = ph.row = 0; ph.sad = 0; ph.valid = 1; continue; }
+                            if (c.prehme_l1_early_exit) {
+                                const PreHme &q = st.prehme[0][ri][sri];
+                                if (li == 1 && q.valid && (q.sad < 32 * 32 || (iabs(q.col) < 16 && iabs(q.row) < 16))) {
+                                    ph.col = (int16_t)-q.col; ph.row = (int16_t)-q.row; ph.sad = q.sad; ph.valid = 1; continue;
                                 }
-                                if (!st.do_ref[li][ri]) { ph.col = ph.row = 0; ph.sad = 0xFFFFFFFFu; continue; }
-                                int sa_w = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.width * f), c.prehme_sa_cfg[sri].sa_max.width);
-                                int sa_h = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.height * f), c.prehme_sa_cfg[sri].sa_max.height);
-                                // prehme_core (:1568-1666)
-                                const DevPlane &rp = p.ref[li][ri].lvl[0];
-                                const int ox16 = (int16_t)st.org_x >> 2, oy16 = (int16_t)st.org_y >> 2;
-                                int ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
-                                clip_axis(ox16, ox, sa_w, rp.org_x - 1, rp.width);
-                                clip_axis(oy16, oy, sa_h, rp.org_y - 1, rp.height);
-                                push_hme_req(st, p, 0, rp, ox16, oy16, (int)st.b64_w >> 2, (int)st.b64_h >> 2, ox, oy, sa_w, sa_h, c.prehme_skip_search_line);
-                                st.ph_req[li][ri][sri] = (uint8_t)st.nreq;
-                                ph.col = (int16_t)ox; ph.row = (int16_t)oy; // search origin until the result is folded in
-                                st.performed_phme[li][ri][sri] = 1;
                             }
+                            if (!st.do_ref[li][ri]) { ph.col = ph.row = 0; ph.sad = 0xFFFFFFFFu; continue; }
+                            int sa_w = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.width * f), c.prehme_sa_cfg[sri].sa_max.width);
+                            int sa_h = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.height * f), c.prehme_sa_cfg[sri].sa_max.height);
+                            // prehme_core (:1568-1666)
+                            const DevPlane &rp = p.ref[li][ri].lvl[0];
+                            const int ox16 = (int16_t)st.org_x >> 2, oy16 = (int16_t)st.org_y >> 2;
+                            int ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
+                            clip_axis(ox16, ox, sa_w, rp.org_x - 1, rp.width);
+                            clip_axis(oy16, oy, sa_h, rp.org_y - 1, rp.height);
+                            push_hme_req(st, p, 0, rp, ox16, oy16, (int)st.b64_w >> 2, (int)st.b64_h >> 2, ox, oy, sa_w, sa_h, c.prehme_skip_search_line);
+                            st.ph_req[li][ri][sri] = (uint8_t)st.nreq;
+                            ph.col = (int16_t)ox; ph.row = (int16_t)oy; // search origin until the result is folded in
+                            st.performed_phme[li][ri][sri] = 1;
                         }
-                }
-                __syncthreads();
-                run_searches(sh PROF_ARG);
-                if (tid == 0) {
-                    for (int li = l_lo; li < l_hi; li++)
-                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
-                            for (int sri = 0; sri < 2; sri++) {
-                                const int k = st.ph_req[li][ri][sri];
-                                if (!k) continue;
-                                PreHme &ph = st.prehme[li][ri][sri];
-                                uint32_t sad; int x, y;
-                                key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
-                                ph.sad = sad;
-                                ph.col = (int16_t)((int16_t)(x + ph.col) * 4);
-                                ph.row = (int16_t)((int16_t)(y + ph.row) * 4);
-                                ph.valid = 1;
-                            }
-                }
-                __syncthreads();
+                    }
             }
+        };
+        auto prehme_post = [&](int bi) {
+            const int l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
+            if (tid == 0) {
+                for (int li = l_lo; li < l_hi; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
+                        for (int sri = 0; sri < 2; sri++) {
+                            const int k = st.ph_req[li][ri][sri];
+                            if (!k) continue;
+                            PreHme &ph = st.prehme[li][ri][sri];
+                            uint32_t sad; int x, y;
+                            key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
+                            ph.sad = sad;
+                            ph.col = (int16_t)((int16_t)(x + ph.col) * 4);
+                            ph.row = (int16_t)((int16_t)(y + ph.row) * 4);
+                            ph.valid = 1;
+                        }
+            }
+        };
+        auto prehme_final = [&]() {
             if (tid == 0) {
                 uint32_t best_sad = 0xFFFFFFFFu;
                 for (int li = 0; li < nl; li++)
@@ -915,305 +917,338 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             if ((uint32_t)((m - best_sad) * 100) > (uint32_t)(c.phme_sad_pct * best_sad)) st.do_ref[li][ri] = 0;
                         }
             }
-            __syncthreads();
-        }
-
-        PROF(3);
-        if (c.enable_hme_flag) {
-            // ---- hme_level0_b64 (motion_estimation.c:1906-2036) ------------------------------------------
-            if (c.enable_hme_level0_flag) {
-                // get_hme_l0_search_area reads list0/ref0's level-0 result only when both thresholds are set
-                const bool dep    = c.enable_me_sr_adjustment && c.distance_based_hme_resizing && c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max;
-                const int  nbatch = dep ? 2 : 1;
-                for (int bi = 0; bi < nbatch; bi++) {
-                    if (tid == 0) {
-                        st.nreq = 0;
-                        const SvtHipSearchAreaMinMax base = st.hme_l0_sa;
-                        for (int li = 0; li < nl; li++)
-                            for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                                if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
-                                st.l0_req[li][ri] = 0;
-                                if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 0, li, ri, 0, 0, 0); continue; }
-                                if (c.prev_me_stage_based_exit_th) {
-                                    const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
-                                    if (st.performed_phme[li][ri][sri] && st.prehme[li][ri][sri].sad < (c.prev_me_stage_based_exit_th >> 4)) {
-                                        set_hme_all(st, p, 0, li, ri, st.prehme[li][ri][sri].col, st.prehme[li][ri][sri].row, st.prehme[li][ri][sri].sad);
-                                        continue;
-                                    }
-                                }
-                                if (!st.do_ref[li][ri]) { set_hme_all(st, p, 0, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
-                                if (!searched(p, li)) continue;
-                                int sa_w = 0, sa_h = 0;
-                                hme_l0_search_area(st, p, li, ri, ref_distance(p, li, ri), sa_w, sa_h);
-                                st.l0_req[li][ri] = (uint8_t)(st.nreq + 1);
-                                for (int h = 0; h < c.num_hme_sa_h; h++)
-                                    for (int w = 0; w < c.num_hme_sa_w; w++) {
-                                        const HmeGeom g = push_hme_level(st, p, 0, p.ref[li][ri].lvl[0], (int16_t)st.org_x >> 2, (int16_t)st.org_y >> 2,
-                                                                         (int)st.b64_w >> 2, (int)st.b64_h >> 2, sa_w, sa_h, 0, 0, w, h);
-                                        st.hx[0][li][ri][w][h] = g.ox; st.hy[0][li][ri][w][h] = g.oy;
-                                    }
-                                if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) st.hme_l0_sa = base;
-                            }
-                    }
-                    __syncthreads();
-                    run_searches(sh PROF_ARG);
-                    if (tid == 0) {
-                        for (int li = 0; li < nl; li++)
-                            for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                                if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
-                                int k = st.l0_req[li][ri];
-                                if (!k) continue;
-                                k--;
-                                for (int h = 0; h < c.num_hme_sa_h; h++)
-                                    for (int w = 0; w < c.num_hme_sa_w; w++, k++) {
-                                        uint32_t sad; int x, y;
-                                        key_to_result(st.req_key[k], full_hme, sad, x, y);
-                                        st.hs[0][li][ri][w][h] = sad;
-                                        st.hx[0][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[0][li][ri][w][h]) * 4);
-                                        st.hy[0][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[0][li][ri][w][h]) * 4);
-                                    }
-                                if (c.prehme_enable) {
-                                    // get_worst_quadrant (:1872-1901): the last compare does not raise the max
-                                    int ww = 0, wh = 0; uint32_t mx = 0;
-                                    if (st.hs[0][li][ri][0][0] > mx) { mx = st.hs[0][li][ri][0][0]; ww = 0; wh = 0; }
-                                    if (st.hs[0][li][ri][1][0] > mx) { mx = st.hs[0][li][ri][1][0]; ww = 1; wh = 0; }
-                                    if (st.hs[0][li][ri][0][1] > mx) { mx = st.hs[0][li][ri][0][1]; ww = 0; wh = 1; }
-                                    if (st.hs[0][li][ri][1][1] > mx) { ww = 1; wh = 1; }
-                                    const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
-                                    if (st.prehme[li][ri][sri].sad < st.hs[0][li][ri][ww][wh]) {
-                                        st.hs[0][li][ri][ww][wh] = st.prehme[li][ri][sri].sad;
-                                        st.hx[0][li][ri][ww][wh] = st.prehme[li][ri][sri].col;
-                                        st.hy[0][li][ri][ww][wh] = st.prehme[li][ri][sri].row;
-                                    }
-                                }
-                            }
-                    }
-                    __syncthreads();
-                }
-            }
-            PROF(4);
-            // ---- hme_level1_b64 / hme_level2_b64 (motion_estimation.c:2041-2177) ----------------------------
-            for (int lvl = 1; lvl <= 2; lvl++) {
-                if (lvl == 1 ? !c.enable_hme_level1_flag : !c.enable_hme_level2_flag) continue;
-                if (tid == 0) {
-                    st.nreq = 0;
-                    for (int i = 0; i < 2 * 4 * 2 * 2; i++) (&st.lvl_req[0][0][0][0])[i] = 0;
-                    for (int li = 0; li < nl; li++)
-                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                            if (!searched(p, li)) continue;
-                            if (lvl == 1) {
-                                if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 1, li, ri, 0, 0, 0); continue; }
-                                if (!st.do_ref[li][ri]) { set_hme_all(st, p, 1, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
-                            }
-                            for (int h = 0; h < c.num_hme_sa_h; h++)
-                                for (int w = 0; w < c.num_hme_sa_w; w++) {
-                                    const uint32_t exit_th = c.prev_me_stage_based_exit_th >> (lvl == 1 ? 5 : 2);
-                                    if (c.prev_me_stage_based_exit_th && st.hs[lvl - 1][li][ri][w][h] < exit_th) {
-                                        st.hx[lvl][li][ri][w][h] = st.hx[lvl - 1][li][ri][w][h];
-                                        st.hy[lvl][li][ri][w][h] = st.hy[lvl - 1][li][ri][w][h];
-                                        st.hs[lvl][li][ri][w][h] = st.hs[lvl - 1][li][ri][w][h];
-                                        continue;
-                                    }
-                                    HmeGeom g;
-                                    if (lvl == 1)
-                                        g = push_hme_level(st, p, 1, p.ref[li][ri].lvl[1], (int16_t)st.org_x >> 1, (int16_t)st.org_y >> 1, (int)st.b64_w >> 1,
-                                                           (int)st.b64_h >> 1, (int16_t)c.hme_l1_sa.width, (int16_t)c.hme_l1_sa.height,
-                                                           st.hx[0][li][ri][w][h] >> 1, st.hy[0][li][ri][w][h] >> 1, 0, 0);
-                                    else
-                                        g = push_hme_level(st, p, 2, p.ref[li][ri].lvl[2], (int16_t)st.org_x, (int16_t)st.org_y, (int)st.b64_w, (int)st.b64_h,
-                                                           (int16_t)c.hme_l2_sa.width, (int16_t)c.hme_l2_sa.height, st.hx[1][li][ri][w][h],
-                                                           st.hy[1][li][ri][w][h], 0, 0);
-                                    st.lvl_req[li][ri][w][h] = (uint8_t)st.nreq;
-                                    st.hx[lvl][li][ri][w][h] = g.ox; st.hy[lvl][li][ri][w][h] = g.oy;
-                                }
-                        }
-                }
-                __syncthreads();
-                run_searches(sh PROF_ARG);
-                if (tid == 0) {
-                    const int scale = (lvl == 1) ? 2 : 1;
-                    for (int li = 0; li < nl; li++)
-                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
-                            for (int h = 0; h < c.num_hme_sa_h; h++)
-                                for (int w = 0; w < c.num_hme_sa_w; w++) {
-                                    const int k = st.lvl_req[li][ri][w][h];
-                                    if (!k) continue;
-                                    uint32_t sad; int x, y;
-                                    key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
-                                    st.hs[lvl][li][ri][w][h] = sad;
-                                    st.hx[lvl][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[lvl][li][ri][w][h]) * scale);
-                                    st.hy[lvl][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[lvl][li][ri][w][h]) * scale);
-                                }
-                }
-                __syncthreads();
-            }
-        }
-
-        PROF(5);
-        // ---- set_final_seach_centre_sb (:2182-2380), hme_prune_ref_and_adjust_sr (:2477-2518) -------------
-        if (tid == 0) {
-            {
-                int16_t cx = 0, cy = 0, sx = 0, sy = 0;
-                u64     hme_sad = 0; // survives across refs, like the reference's local
+        };
+        // ---- hme_level0_b64 (motion_estimation.c:1906-2036) ------------------------------------------
+        // get_hme_l0_search_area reads list0/ref0's level-0 result only when both thresholds are set
+        const bool l0_dep = c.enable_me_sr_adjustment && c.distance_based_hme_resizing && c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max;
+        auto l0_pre = [&](int bi) {
+            const bool dep = l0_dep;
+            if (tid == 0) {
+                st.nreq = 0;
+                const SvtHipSearchAreaMinMax base = st.hme_l0_sa;
                 for (int li = 0; li < nl; li++)
                     for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (searched(p, li)) {
-                            if (c.enable_hme_flag) {
-                                int lvl = -1;
-                                if (c.enable_hme_level0_flag && !c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 0;
-                                if (c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 1;
-                                if (c.enable_hme_level2_flag) lvl = 2;
-                                if (lvl >= 0) {
-                                    cx = st.hx[lvl][li][ri][0][0]; cy = st.hy[lvl][li][ri][0][0]; hme_sad = st.hs[lvl][li][ri][0][0];
-                                    int w = 1;
-                                    for (int h = 0; h < c.num_hme_sa_h; h++) {
-                                        for (; w < c.num_hme_sa_w; w++)
-                                            if (st.hs[lvl][li][ri][w][h] < hme_sad) {
-                                                cx = st.hx[lvl][li][ri][w][h]; cy = st.hy[lvl][li][ri][w][h]; hme_sad = st.hs[lvl][li][ri][w][h];
-                                            }
-                                        w = 0;
-                                    }
-                                }
-                                sx = cx; sy = cy;
+                        if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
+                        st.l0_req[li][ri] = 0;
+                        if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 0, li, ri, 0, 0, 0); continue; }
+                        if (c.prev_me_stage_based_exit_th) {
+                            const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
+                            if (st.performed_phme[li][ri][sri] && st.prehme[li][ri][sri].sad < (c.prev_me_stage_based_exit_th >> 4)) {
+                                set_hme_all(st, p, 0, li, ri, st.prehme[li][ri][sri].col, st.prehme[li][ri][sri].row, st.prehme[li][ri][sri].sad);
+                                continue;
                             }
-                        } else { sx = sy = 0; }
-                        st.hme_sc_x[li][ri] = sx; st.hme_sc_y[li][ri] = sy; st.hme_sad64[li][ri] = hme_sad;
+                        }
+                        if (!st.do_ref[li][ri]) { set_hme_all(st, p, 0, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
+                        if (!searched(p, li)) continue;
+                        int sa_w = 0, sa_h = 0;
+                        hme_l0_search_area(st, p, li, ri, ref_distance(p, li, ri), sa_w, sa_h);
+                        st.l0_req[li][ri] = (uint8_t)(st.nreq + 1);
+                        for (int h = 0; h < c.num_hme_sa_h; h++)
+                            for (int w = 0; w < c.num_hme_sa_w; w++) {
+                                const HmeGeom g = push_hme_level(st, p, 0, p.ref[li][ri].lvl[0], (int16_t)st.org_x >> 2, (int16_t)st.org_y >> 2,
+                                                                 (int)st.b64_w >> 2, (int)st.b64_h >> 2, sa_w, sa_h, 0, 0, w, h);
+                                st.hx[0][li][ri][w][h] = g.ox; st.hy[0][li][ri][w][h] = g.oy;
+                            }
+                        if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) st.hme_l0_sa = base;
                     }
             }
-            if (c.enable_hme_flag) {
-                const uint16_t th = c.prune_ref_if_hme_sad_dev_bigger_than_th;
-                if (c.enable_me_hme_ref_pruning && th != 0xFFFF) {
-                    u64 best = ~0ull;
-                    for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) best = st.hme_sad64[li][ri] < best ? st.hme_sad64[li][ri] : best;
-                    for (int li = 0; li < 2; li++) for (int ri = 1; ri < 4; ri++)
-                        if ((st.hme_sad64[li][ri] - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
+        };
+        auto l0_post = [&](int bi) {
+            const bool dep = l0_dep;
+            if (tid == 0) {
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
+                        int k = st.l0_req[li][ri];
+                        if (!k) continue;
+                        k--;
+                        for (int h = 0; h < c.num_hme_sa_h; h++)
+                            for (int w = 0; w < c.num_hme_sa_w; w++, k++) {
+                                uint32_t sad; int x, y;
+                                key_to_result(st.req_key[k], full_hme, sad, x, y);
+                                st.hs[0][li][ri][w][h] = sad;
+                                st.hx[0][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[0][li][ri][w][h]) * 4);
+                                st.hy[0][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[0][li][ri][w][h]) * 4);
+                            }
+                        if (c.prehme_enable) {
+                            // get_worst_quadrant (:1872-1901): the last compare does not raise the max
+                            int ww = 0, wh = 0; uint32_t mx = 0;
+                            if (st.hs[0][li][ri][0][0] > mx) { mx = st.hs[0][li][ri][0][0]; ww = 0; wh = 0; }
+                            if (st.hs[0][li][ri][1][0] > mx) { mx = st.hs[0][li][ri][1][0]; ww = 1; wh = 0; }
+                            if (st.hs[0][li][ri][0][1] > mx) { mx = st.hs[0][li][ri][0][1]; ww = 0; wh = 1; }
+                            if (st.hs[0][li][ri][1][1] > mx) { ww = 1; wh = 1; }
+                            const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
+                            if (st.prehme[li][ri][sri].sad < st.hs[0][li][ri][ww][wh]) {
+                                st.hs[0][li][ri][ww][wh] = st.prehme[li][ri][sri].sad;
+                                st.hx[0][li][ri][ww][wh] = st.prehme[li][ri][sri].col;
+                                st.hy[0][li][ri][ww][wh] = st.prehme[li][ri][sri].row;
+                            }
+                        }
+                    }
+            }
+        };
+        // ---- hme_level1_b64 / hme_level2_b64 (motion_estimation.c:2041-2177) ----------------------------
+        auto lvl_pre = [&](int lvl) {
+            if (tid == 0) {
+                st.nreq = 0;
+                for (int i = 0; i < 2 * 4 * 2 * 2; i++) (&st.lvl_req[0][0][0][0])[i] = 0;
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        if (!searched(p, li)) continue;
+                        if (lvl == 1) {
+                            if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 1, li, ri, 0, 0, 0); continue; }
+                            if (!st.do_ref[li][ri]) { set_hme_all(st, p, 1, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
+                        }
+                        for (int h = 0; h < c.num_hme_sa_h; h++)
+                            for (int w = 0; w < c.num_hme_sa_w; w++) {
+                                const uint32_t exit_th = c.prev_me_stage_based_exit_th >> (lvl == 1 ? 5 : 2);
+                                if (c.prev_me_stage_based_exit_th && st.hs[lvl - 1][li][ri][w][h] < exit_th) {
+                                    st.hx[lvl][li][ri][w][h] = st.hx[lvl - 1][li][ri][w][h];
+                                    st.hy[lvl][li][ri][w][h] = st.hy[lvl - 1][li][ri][w][h];
+                                    st.hs[lvl][li][ri][w][h] = st.hs[lvl - 1][li][ri][w][h];
+                                    continue;
+                                }
+                                HmeGeom g;
+                                if (lvl == 1)
+                                    g = push_hme_level(st, p, 1, p.ref[li][ri].lvl[1], (int16_t)st.org_x >> 1, (int16_t)st.org_y >> 1, (int)st.b64_w >> 1,
+                                                       (int)st.b64_h >> 1, (int16_t)c.hme_l1_sa.width, (int16_t)c.hme_l1_sa.height,
+                                                       st.hx[0][li][ri][w][h] >> 1, st.hy[0][li][ri][w][h] >> 1, 0, 0);
+                                else
+                                    g = push_hme_level(st, p, 2, p.ref[li][ri].lvl[2], (int16_t)st.org_x, (int16_t)st.org_y, (int)st.b64_w, (int)st.b64_h,
+                                                       (int16_t)c.hme_l2_sa.width, (int16_t)c.hme_l2_sa.height, st.hx[1][li][ri][w][h],
+                                                       st.hy[1][li][ri][w][h], 0, 0);
+                                st.lvl_req[li][ri][w][h] = (uint8_t)st.nreq;
+                                st.hx[lvl][li][ri][w][h] = g.ox; st.hy[lvl][li][ri][w][h] = g.oy;
+                            }
+                    }
+            }
+        };
+        auto lvl_post = [&](int lvl) {
+            if (tid == 0) {
+                const int scale = (lvl == 1) ? 2 : 1;
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
+                        for (int h = 0; h < c.num_hme_sa_h; h++)
+                            for (int w = 0; w < c.num_hme_sa_w; w++) {
+                                const int k = st.lvl_req[li][ri][w][h];
+                                if (!k) continue;
+                                uint32_t sad; int x, y;
+                                key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
+                                st.hs[lvl][li][ri][w][h] = sad;
+                                st.hx[lvl][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[lvl][li][ri][w][h]) * scale);
+                                st.hy[lvl][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[lvl][li][ri][w][h]) * scale);
+                            }
+            }
+        };
+        // ---- set_final_seach_centre_sb (:2182-2380), hme_prune_ref_and_adjust_sr (:2477-2518) -------------
+        auto centre = [&]() {
+            if (tid == 0) {
+                {
+                    int16_t cx = 0, cy = 0, sx = 0, sy = 0;
+                    u64     hme_sad = 0; // survives across refs, like the reference's local
+                    for (int li = 0; li < nl; li++)
+                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                            if (searched(p, li)) {
+                                if (c.enable_hme_flag) {
+                                    int lvl = -1;
+                                    if (c.enable_hme_level0_flag && !c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 0;
+                                    if (c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 1;
+                                    if (c.enable_hme_level2_flag) lvl = 2;
+                                    if (lvl >= 0) {
+                                        cx = st.hx[lvl][li][ri][0][0]; cy = st.hy[lvl][li][ri][0][0]; hme_sad = st.hs[lvl][li][ri][0][0];
+                                        int w = 1;
+                                        for (int h = 0; h < c.num_hme_sa_h; h++) {
+                                            for (; w < c.num_hme_sa_w; w++)
+                                                if (st.hs[lvl][li][ri][w][h] < hme_sad) {
+                                                    cx = st.hx[lvl][li][ri][w][h]; cy = st.hy[lvl][li][ri][w][h]; hme_sad = st.hs[lvl][li][ri][w][h];
+                                                }
+                                            w = 0;
+                                        }
+                                    }
+                                    sx = cx; sy = cy;
+                                }
+                            } else { sx = sy = 0; }
+                            st.hme_sc_x[li][ri] = sx; st.hme_sc_y[li][ri] = sy; st.hme_sad64[li][ri] = hme_sad;
+                        }
                 }
-                if (c.enable_me_sr_adjustment)
-                    for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) {
-                        if (iabs(st.hme_sc_x[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th && iabs(st.hme_sc_y[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th &&
-                            st.hme_sad64[li][ri] < c.stationary_hme_sad_abs_th)
-                            st.sr_divisor[li][ri] = c.stationary_me_sr_divisor;
-                        else if (st.hme_sad64[li][ri] < c.reduce_me_sr_based_on_hme_sad_abs_th)
-                            st.sr_divisor[li][ri] = c.me_sr_divisor_for_low_hme_sad;
+                if (c.enable_hme_flag) {
+                    const uint16_t th = c.prune_ref_if_hme_sad_dev_bigger_than_th;
+                    if (c.enable_me_hme_ref_pruning && th != 0xFFFF) {
+                        u64 best = ~0ull;
+                        for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) best = st.hme_sad64[li][ri] < best ? st.hme_sad64[li][ri] : best;
+                        for (int li = 0; li < 2; li++) for (int ri = 1; ri < 4; ri++)
+                            if ((st.hme_sad64[li][ri] - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
                     }
+                    if (c.enable_me_sr_adjustment)
+                        for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) {
+                            if (iabs(st.hme_sc_x[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th && iabs(st.hme_sc_y[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th &&
+                                st.hme_sad64[li][ri] < c.stationary_hme_sad_abs_th)
+                                st.sr_divisor[li][ri] = c.stationary_me_sr_divisor;
+                            else if (st.hme_sad64[li][ri] < c.reduce_me_sr_based_on_hme_sad_abs_th)
+                                st.sr_divisor[li][ri] = c.me_sr_divisor_for_low_hme_sad;
+                        }
+                }
             }
-        }
-        __syncthreads();
-
-        PROF(6);
+        };
         // ---- integer_search_b64 (motion_estimation.c:1249-1516) --------------------------------------------
         // Refs are independent except through p_sb_best_sad[0][0][0] when enable_me_sr_adjustment == 2 (and the
         // zz early exit is off); then list0/ref0 is finished first.  Per group: (a) check_00_center SADs,
         // (b) search-area sizing and the 1-point probe for the 8x8-variance test, (c) final window, full search.
-        {
-            const bool dep    = (!c.me_early_exit_th) && c.enable_me_sr_adjustment == 2;
-            const int  ngroup = dep ? 2 : 1;
-            for (int gi = 0; gi < ngroup; gi++) {
-                if (tid == 0) {
-                    st.nreq = 0;
-                    for (int li = 0; li < nl; li++)
-                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                            if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
-                            st.c00_req[li][ri] = 0;
-                            st.me_cx[li][ri] = st.hme_sc_x[li][ri]; st.me_cy[li][ri] = st.hme_sc_y[li][ri];
-                            if (c.me_early_exit_th || !st.do_ref[li][ri]) continue;
-                            int16_t cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
-                            if ((cx != 0 || cy != 0) && d.is_ref) { // check_00_center (:1139-1206)
-                                const DevPlane &rp = p.ref[li][ri].lvl[2];
-                                const int ox = (int16_t)st.org_x, oy = (int16_t)st.org_y;
-                                if (ox + cx < -63) cx = (int16_t)(-63 - ox);
-                                if (ox + cx > rp.width - 1) cx = (int16_t)(cx - ((ox + cx) - (rp.width - 1)));
-                                if (oy + cy < -63) cy = (int16_t)(-63 - oy);
-                                if (oy + cy > rp.height - 1) cy = (int16_t)(cy - ((oy + cy) - (rp.height - 1)));
-                                st.me_cx[li][ri] = cx; st.me_cy[li][ri] = cy;
-                                push_zz_req(st, rp, 0, 0);
-                                push_zz_req(st, rp, cx, cy);
-                                st.c00_req[li][ri] = (uint8_t)st.nreq; // index of the second request + 1
-                            }
-                        }
-                }
-                __syncthreads();
-                PROF(7);
-                if (st.nreq) run_searches(sh PROF_ARG); // uniform (LDS value read after the barrier)
-                PROF(8);
-                if (tid == 0) {
-                    st.nme = 0; st.nprobe = 0;
-                    for (int li = 0; li < nl; li++)
-                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                            if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
-                            if (!st.do_ref[li][ri]) continue;
+        const bool me_dep = (!c.me_early_exit_th) && c.enable_me_sr_adjustment == 2;
+        auto c00_pre = [&](int gi) {
+            const bool dep = me_dep;
+            if (tid == 0) {
+                st.nreq = 0;
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
+                        st.c00_req[li][ri] = 0;
+                        st.me_cx[li][ri] = st.hme_sc_x[li][ri]; st.me_cy[li][ri] = st.hme_sc_y[li][ri];
+                        if (c.me_early_exit_th || !st.do_ref[li][ri]) continue;
+                        int16_t cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
+                        if ((cx != 0 || cy != 0) && d.is_ref) { // check_00_center (:1139-1206)
                             const DevPlane &rp = p.ref[li][ri].lvl[2];
-                            int16_t  cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
-                            const uint32_t dist = (uint16_t)scaled_distance(ref_distance(p, li, ri));
-                            int16_t sa_w = (int16_t)imin((int)(c.me_sa.sa_min.width * dist), c.me_sa.sa_max.width);
-                            int16_t sa_h = (int16_t)imin((int)(c.me_sa.sa_min.height * dist), c.me_sa.sa_max.height);
-                            if (c.mv_sa_adj_enabled && (!c.mv_sa_adj_nearest_ref_only || ri == 0)) {
-                                if (iabs(st.hme_sc_x[li][ri]) > c.mv_sa_adj_mv_size_th) sa_w = (int16_t)(sa_w * c.mv_sa_adj_sa_multiplier);
-                                if (iabs(st.hme_sc_y[li][ri]) > c.mv_sa_adj_mv_size_th) sa_h = (int16_t)(sa_h * c.mv_sa_adj_sa_multiplier);
-                            }
-                            { const uint32_t q = (uint32_t)(int)sa_w / st.sr_divisor[li][ri]; sa_w = (int16_t)(((q > 1u ? q : 1u) + 7) & ~7u); }
-                            { const uint32_t q = (uint32_t)(int)sa_h / st.sr_divisor[li][ri]; sa_h = (int16_t)(q > 3u ? q : 3u); }
-                            const int16_t h0 = sa_h, w0 = sa_w;
-                            u64 best_hme_sad = ~0ull;
-                            if (c.me_early_exit_th) {
-                                if (st.zz_sad[li][ri] < c.me_early_exit_th / 6) sa_w = sa_h = 1;
-                            } else {
-                                int accurate = 1;
-                                const int k2 = st.c00_req[li][ri];
-                                if (k2) {
-                                    const uint32_t zero = (uint32_t)(st.req_key[k2 - 2] >> 32) << 1;
-                                    const uint32_t hme  = (uint32_t)(st.req_key[k2 - 1] >> 32) << 1;
-                                    if (zero <= hme) cx = cy = 0; // MIN(zero_cost, hme_cost) == zero_cost
-                                    best_hme_sad = hme;
-                                    if (cx == 0 && cy == 0) accurate = 0;
-                                }
-                                if (c.enable_me_sr_adjustment == 2) {
-                                    if ((accurate && best_hme_sad < 24 * 24) || (d.is_ref && st.hme_sad64[li][ri] < 24 * 24)) sa_h = (int16_t)(sa_h / 2);
-                                    if ((li || ri) && st.best_sad[0][0][0] < 5000 && sa_h == h0 && sa_w == w0) { sa_h = (int16_t)(sa_h >> 1); sa_w = (int16_t)(sa_w >> 1); }
-                                }
-                            }
-                            MeReq &m = st.me[st.nme++];
-                            m.pix0 = plane_at(rp, (int)st.org_x, (int)st.org_y); m.stride = rp.stride;
-                            m.li = (uint8_t)li; m.ri = (uint8_t)ri; m.pad = 0;
-                            m.sa_w = sa_w; m.sa_h = sa_h; // provisional size, finalised after the probe
-                            m.ox = cx; m.oy = cy;         // the search centre until then
-                            m.probe = (c.me_8x8_var_enabled && sa_w * sa_h > 24) ? 1 : 0;
-                            if (m.probe) { MeReq &pr = st.me_probe[st.nprobe++]; pr = m; pr.sa_w = pr.sa_h = 1; }
+                            const int ox = (int16_t)st.org_x, oy = (int16_t)st.org_y;
+                            if (ox + cx < -63) cx = (int16_t)(-63 - ox);
+                            if (ox + cx > rp.width - 1) cx = (int16_t)(cx - ((ox + cx) - (rp.width - 1)));
+                            if (oy + cy < -63) cy = (int16_t)(-63 - oy);
+                            if (oy + cy > rp.height - 1) cy = (int16_t)(cy - ((oy + cy) - (rp.height - 1)));
+                            st.me_cx[li][ri] = cx; st.me_cy[li][ri] = cy;
+                            push_zz_req(st, rp, 0, 0);
+                            push_zz_req(st, rp, cx, cy);
+                            st.c00_req[li][ri] = (uint8_t)st.nreq; // index of the second request + 1
                         }
-                }
-                __syncthreads();
-                PROF(9);
-                if (st.nprobe) run_me_searches(sh, p, st.me_probe, st.nprobe); // uniform
-                PROF(10);
-                if (tid == 0) {
-                    const int pic_w = (int16_t)d.aligned_width, pic_h = (int16_t)d.aligned_height;
-                    for (int i = 0; i < st.nme; i++) {
-                        MeReq &m = st.me[i];
-                        int16_t sa_w = m.sa_w, sa_h = m.sa_h;
-                        const int cx = m.ox, cy = m.oy;
-                        if (m.probe) { // :1391-1439 -- only one point was searched: 64x64 SAD == sum of the 8x8 SADs
-                            const uint32_t *b8 = &st.best_sad[m.li][m.ri][21];
-                            const uint32_t  mean = st.best_sad[m.li][m.ri][0] / 64;
-                            uint32_t ssq = 0;
-                            for (int k = 0; k < 64; k++) { const int32_t dd = (int32_t)b8[k] - (int32_t)mean; ssq += (uint32_t)(dd * dd); }
-                            const uint32_t var = ssq / 64;
-                            if (var > c.me_sr_mult2_th) { sa_w = (int16_t)((imax(1, sa_w * 3 / 2) + 7) & ~7); sa_h = (int16_t)imax(1, sa_h * 3 / 2); }
-                            if (var < c.me_sr_div4_th) { sa_w = (int16_t)((imax(1, sa_w >> 2) + 7) & ~7); sa_h = (int16_t)imax(3, imax(1, sa_h >> 2)); }
-                            else if (var < c.me_sr_div2_th) { sa_w = (int16_t)((imin(sa_w, sa_w >> 1) + 7) & ~7); sa_h = (int16_t)imax(3, imin(sa_h, sa_h >> 1)); }
-                        }
-                        int ox = (int16_t)(cx - (sa_w >> 1)), oy = (int16_t)(cy - (sa_h >> 1)), w = sa_w, h = sa_h;
-                        clip_axis((int16_t)st.org_x, ox, w, 63, pic_w);
-                        w = (w < 8) ? w : (w & ~7);
-                        clip_axis((int16_t)st.org_y, oy, h, 63, pic_h);
-                        m.ox = (int16_t)ox; m.oy = (int16_t)oy; m.sa_w = (int16_t)w; m.sa_h = (int16_t)h;
                     }
-                }
-                __syncthreads();
-                PROF(11);
-                run_me_searches(sh, p, st.me, st.nme);
-                PROF(12);
             }
+        };
+        auto probe_pre = [&](int gi) {
+            const bool dep = me_dep;
+            if (tid == 0) {
+                st.nme = 0; st.nprobe = 0;
+                for (int li = 0; li < nl; li++)
+                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
+                        if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
+                        if (!st.do_ref[li][ri]) continue;
+                        const DevPlane &rp = p.ref[li][ri].lvl[2];
+                        int16_t  cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
+                        const uint32_t dist = (uint16_t)scaled_distance(ref_distance(p, li, ri));
+                        int16_t sa_w = (int16_t)imin((int)(c.me_sa.sa_min.width * dist), c.me_sa.sa_max.width);
+                        int16_t sa_h = (int16_t)imin((int)(c.me_sa.sa_min.height * dist), c.me_sa.sa_max.height);
+                        if (c.mv_sa_adj_enabled && (!c.mv_sa_adj_nearest_ref_only || ri == 0)) {
+                            if (iabs(st.hme_sc_x[li][ri]) > c.mv_sa_adj_mv_size_th) sa_w = (int16_t)(sa_w * c.mv_sa_adj_sa_multiplier);
+                            if (iabs(st.hme_sc_y[li][ri]) > c.mv_sa_adj_mv_size_th) sa_h = (int16_t)(sa_h * c.mv_sa_adj_sa_multiplier);
+                        }
+                        { const uint32_t q = (uint32_t)(int)sa_w / st.sr_divisor[li][ri]; sa_w = (int16_t)(((q > 1u ? q : 1u) + 7) & ~7u); }
+                        { const uint32_t q = (uint32_t)(int)sa_h / st.sr_divisor[li][ri]; sa_h = (int16_t)(q > 3u ? q : 3u); }
+                        const int16_t h0 = sa_h, w0 = sa_w;
+                        u64 best_hme_sad = ~0ull;
+                        if (c.me_early_exit_th) {
+                            if (st.zz_sad[li][ri] < c.me_early_exit_th / 6) sa_w = sa_h = 1;
+                        } else {
+                            int accurate = 1;
+                            const int k2 = st.c00_req[li][ri];
+                            if (k2) {
+                                const uint32_t zero = (uint32_t)(st.req_key[k2 - 2] >> 32) << 1;
+                                const uint32_t hme  = (uint32_t)(st.req_key[k2 - 1] >> 32) << 1;
+                                if (zero <= hme) cx = cy = 0; // MIN(zero_cost, hme_cost) == zero_cost
+                                best_hme_sad = hme;
+                                if (cx == 0 && cy == 0) accurate = 0;
+                            }
+                            if (c.enable_me_sr_adjustment == 2) {
+                                if ((accurate && best_hme_sad < 24 * 24) || (d.is_ref && st.hme_sad64[li][ri] < 24 * 24)) sa_h = (int16_t)(sa_h / 2);
+                                if ((li || ri) && st.best_sad[0][0][0] < 5000 && sa_h == h0 && sa_w == w0) { sa_h = (int16_t)(sa_h >> 1); sa_w = (int16_t)(sa_w >> 1); }
+                            }
+                        }
+                        MeReq &m = st.me[st.nme++];
+                        m.pix0 = plane_at(rp, (int)st.org_x, (int)st.org_y); m.stride = rp.stride;
+                        m.li = (uint8_t)li; m.ri = (uint8_t)ri; m.pad = 0;
+                        m.sa_w = sa_w; m.sa_h = sa_h; // provisional size, finalised after the probe
+                        m.ox = cx; m.oy = cy;         // the search centre until then
+                        m.probe = (c.me_8x8_var_enabled && sa_w * sa_h > 24) ? 1 : 0;
+                        if (m.probe) { MeReq &pr = st.me_probe[st.nprobe++]; pr = m; pr.sa_w = pr.sa_h = 1; }
+                    }
+            }
+        };
+        auto main_pre = [&]() {
+            if (tid == 0) {
+                const int pic_w = (int16_t)d.aligned_width, pic_h = (int16_t)d.aligned_height;
+                for (int i = 0; i < st.nme; i++) {
+                    MeReq &m = st.me[i];
+                    int16_t sa_w = m.sa_w, sa_h = m.sa_h;
+                    const int cx = m.ox, cy = m.oy;
+                    if (m.probe) { // :1391-1439 -- only one point was searched: 64x64 SAD == sum of the 8x8 SADs
+                        const uint32_t *b8 = &st.best_sad[m.li][m.ri][21];
+                        const uint32_t  mean = st.best_sad[m.li][m.ri][0] / 64;
+                        uint32_t ssq = 0;
+                        for (int k = 0; k < 64; k++) { const int32_t dd = (int32_t)b8[k] - (int32_t)mean; ssq += (uint32_t)(dd * dd); }
+                        const uint32_t var = ssq / 64;
+                        if (var > c.me_sr_mult2_th) { sa_w = (int16_t)((imax(1, sa_w * 3 / 2) + 7) & ~7); sa_h = (int16_t)imax(1, sa_h * 3 / 2); }
+                        if (var < c.me_sr_div4_th) { sa_w = (int16_t)((imax(1, sa_w >> 2) + 7) & ~7); sa_h = (int16_t)imax(3, imax(1, sa_h >> 2)); }
+                        else if (var < c.me_sr_div2_th) { sa_w = (int16_t)((imin(sa_w, sa_w >> 1) + 7) & ~7); sa_h = (int16_t)imax(3, imin(sa_h, sa_h >> 1)); }
+                    }
+                    int ox = (int16_t)(cx - (sa_w >> 1)), oy = (int16_t)(cy - (sa_h >> 1)), w = sa_w, h = sa_h;
+                    clip_axis((int16_t)st.org_x, ox, w, 63, pic_w);
+                    w = (w < 8) ? w : (w & ~7);
+                    clip_axis((int16_t)st.org_y, oy, h, 63, pic_h);
+                    m.ox = (int16_t)ox; m.oy = (int16_t)oy; m.sa_w = (int16_t)w; m.sa_h = (int16_t)h;
+                }
+            }
+        };
+
+        enum { kZz, kPrehme, kL0, kL1, kL2, kC00, kProbe, kMain, kEnd };
+        const int n_prehme = c.prehme_l1_early_exit ? nl : 1, n_l0 = l0_dep ? 2 : 1, n_group = me_dep ? 2 : 1;
+        int step = kZz, bi = 0; // uniform: derived from launch parameters only
+        PROF(2);
+        while (step != kEnd) {
+            bool run = true;
+            switch (step) {
+            case kZz: run = c.me_early_exit_th || c.me_safe_limit_zz_th; if (run) zz_pre(); break;
+            case kPrehme: run = c.prehme_enable; if (run) prehme_pre(bi); break;
+            case kL0: run = c.enable_hme_flag && c.enable_hme_level0_flag; if (run) l0_pre(bi); break;
+            case kL1: run = c.enable_hme_flag && c.enable_hme_level1_flag; if (run) lvl_pre(1); break;
+            case kL2: run = c.enable_hme_flag && c.enable_hme_level2_flag; if (run) lvl_pre(2); break;
+            case kC00: if (bi == 0) centre(); c00_pre(bi); break;
+            case kProbe: probe_pre(bi); break;
+            default: main_pre(); break;
+            }
+            if (run) {
+                __syncthreads();
+                PROF(3);
+                if (step < kProbe) {
+                    if (st.nreq) run_searches(sh PROF_ARG); // uniform (LDS value read after the barrier)
+                } else {
+                    const bool   probe = step == kProbe;
+                    const MeReq *list  = probe ? st.me_probe : st.me;
+                    const int    count = probe ? st.nprobe : st.nme;
+                    run_me_searches(sh, p, list, count);
+                }
+                PROF(4);
+            }
+            switch (step) { // fold the results in, pick the next stage
+            case kZz: if (run) zz_post(); step = kPrehme; break;
+            case kPrehme:
+                if (run) prehme_post(bi);
+                if (run && bi + 1 < n_prehme) { bi++; break; }
+                if (run) prehme_final();
+                step = kL0; bi = 0;
+                break;
+            case kL0:
+                if (run) l0_post(bi);
+                if (run && bi + 1 < n_l0) { bi++; break; }
+                step = kL1; bi = 0;
+                break;
+            case kL1: if (run) lvl_post(1); step = kL2; break;
+            case kL2: if (run) lvl_post(2); step = kC00; break;
+            case kC00: step = kProbe; break;
+            case kProbe: step = kMain; break;
+            default:
+                if (bi + 1 < n_group) { bi++; step = kC00; } else step = kEnd;
+                break;
+            }
+            if (run && step != kProbe && step != kMain) __syncthreads(); // the probe / final-window plans read what lane 0 itself wrote
+            PROF(5);
         }
+
 
         // ---- me_prune_ref (motion_estimation.c:1522-1565) ----------------------------------------------------
         if (c.enable_hme_flag && c.enable_me_hme_ref_pruning) {
@@ -1244,7 +1279,6 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             uint32_t *o_mv    = p.res.me_mv_array + (size_t)b * n_pu * d.max_refs;
             uint8_t  *o_cand  = p.res.me_candidate_array + (size_t)b * n_pu * d.max_cand;
             const int r0 = d.num_of_ref_pic_to_search[0], r1 = d.num_of_ref_pic_to_search[1];
-            const int n  = tid;
             auto use_pu = [&](int nn) { return d.enable_me_16x16 ? (d.enable_me_8x8 || nn < 21) : nn < 5; };
             auto pack   = [](unsigned dir, unsigned i0, unsigned i1, unsigned l0, unsigned l1) {
                 return (uint8_t)((dir & 3) | ((i0 & 3) << 2) | ((i1 & 3) << 4) | ((l0 & 1) << 6) | ((l1 & 1) << 7));
@@ -1254,7 +1288,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             for (int i = tid; i < (int)(n_pu * d.max_cand); i += kThreads) o_cand[i] = 0;
             for (int i = tid; i < (int)n_pu; i += kThreads) o_total[i] = 0;
             __syncthreads();
-            if (n < d.max_number_of_pus_per_sb) {
+            for (int n = tid; n < d.max_number_of_pus_per_sb; n += kThreads) {
                 const int use = use_pu(n);
                 uint32_t  nls = nl;
                 if (r0 == 1 && r1 == 0) { // construct_me_candidate_array_single_ref
@@ -1429,7 +1463,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, uint32_t
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    uint32_t grid = (uint32_t)ctx->num_cus * 4u; // 4 workgroups per CU: <= 128 VGPRs (launch bounds) and <= 40 KiB LDS each
+    uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)SVT_HIP_ME_WG_PER_CU; // persistent workgroups: what the launch bounds and the LDS footprint keep resident
     if (grid > n_jobs) grid = n_jobs;
     // parameter block -> HBM (stream ordered: the previous launch has consumed the buffer before this copy lands)
     SVT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->me_params, params, sizeof(MeKernelParams), hipMemcpyHostToDevice, ctx->stream));
