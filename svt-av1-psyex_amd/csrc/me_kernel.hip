@@ -68,15 +68,19 @@ struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
     int16_t        pad1;
 };
 
-struct Tile { // a rectangle of a Req whose window fits the LDS arena
-    uint8_t  req, narrow;
+struct Tile { // a rectangle of a Req whose window fits the LDS arena (carries what staging / evaluation need: one LDS read)
+    const uint8_t *g0;     // 16-byte aligned global address of LDS byte 0 of the tile's first row
+    uint32_t stride;
+    uint32_t lds_off;      // byte offset in the arena
+    uint8_t  req, narrow, bw, bh; // request index; block geometry copied from the request
+    uint8_t  rs, level, skip_even, pad;
     int16_t  x0, y0, w, h; // sub-area of the search area
     uint16_t pitch;        // LDS row pitch in bytes (multiple of 16)
     uint16_t shift;        // position x0 sits at LDS byte `shift` of a row
-    uint32_t lds_off;      // byte offset in the arena
-    uint32_t rows;         // window rows staged
     uint32_t item0, nitems, ng;
     uint32_t vec0;         // index of this tile's first 16-byte vector in the batch's flattened staging order
+    uint32_t slices;       // narrow: block rows per position (one item each), else 1
+    uint32_t ng_magic, slice_magic, vpr_magic; // magic_of(ng), magic_of(slices), magic_of(pitch / 16)
 };
 
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
@@ -112,7 +116,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     uint8_t  lvl_req[2][4][2][2];
     uint8_t  c00_req[2][4];
     // batch machinery
-    int      nreq, ntile, next_req, next_x, next_y, nitems, nvec, cur_tw, cur_th;
+    int      nreq, ntile, next_req, next_x, next_y, nitems, nvec, cur_tw, cur_th, last;
     Req      req[kMaxReq];
     u64      req_key[kMaxReq];
     Tile     tile[kMaxReq];
@@ -135,6 +139,8 @@ struct Shared {
     uint8_t src16[16 * 16];
     __attribute__((aligned(16))) uint8_t win[kWinBytes];
 };
+
+static_assert(sizeof(Shared) * SVT_HIP_ME_WG_PER_CU <= 160 * 1024, "the planned workgroups per CU must fit the 160 KiB LDS");
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -164,15 +170,42 @@ __device__ __forceinline__ const uint8_t *plane_at(const DevPlane &pl, int x, in
 // Batched SAD searches
 // ---------------------------------------------------------------------------------------------
 
+// exact k / d for k, d < 65536 through one multiply: magic_of(d) = ceil(2^32 / d) (0 stands for d == 1)
+__device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d <= 1u ? 0u : 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ uint32_t div_by_magic(uint32_t k, uint32_t m) { return m ? __umulhi(k, m) : k; }
+
 // bytes of LDS a tile of w x h positions needs (worst-case 16-byte phase when shift < 0)
 __device__ __forceinline__ uint32_t tile_bytes(const Req &r, int shift, int w, int h) {
     const int sh = shift < 0 ? 15 : shift;
     return (uint32_t)(((sh + w - 1 + r.bw + 15) & ~15) + 16) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
 }
 
+__device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, int x0, int y0, int w, int h, int shift, uint32_t lds_off,
+                                          uint32_t item0, uint32_t vec0) {
+    const int narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
+    t.g0        = r.win + x0 + (long long)y0 * r.stride - shift;
+    t.stride    = r.stride;
+    t.lds_off   = lds_off;
+    t.req       = (uint8_t)req_idx;
+    t.narrow    = (uint8_t)narrow;
+    t.bw = r.bw; t.bh = r.bh; t.rs = r.rs; t.level = r.level; t.skip_even = r.skip_even; t.pad = 0;
+    t.x0 = (int16_t)x0; t.y0 = (int16_t)y0; t.w = (int16_t)w; t.h = (int16_t)h;
+    t.pitch     = (uint16_t)(((shift + w - 1 + r.bw + 15) & ~15) + 16);
+    t.shift     = (uint16_t)shift;
+    t.ng        = (uint32_t)((shift & 3) + w + 3) >> 2;
+    t.slices    = narrow ? r.bh : 1u;
+    t.item0     = item0;
+    t.nitems    = t.ng * (uint32_t)h * t.slices;
+    t.vec0      = vec0;
+    t.ng_magic    = magic_of(t.ng);
+    t.slice_magic = magic_of(t.slices);
+    t.vpr_magic   = magic_of((uint32_t)t.pitch >> 4);
+}
+
 // lane 0: cut the pending requests into tiles whose reference windows fit the LDS arena.  Every request is
 // cut on a fixed (cur_tw x cur_th) grid chosen so that any of its tiles fits an empty arena.
-__device__ void plan_tiles(St &st) {
+__device__ void plan_tiles(St &st, bool first) {
+    if (first) { st.next_req = 0; st.next_x = 0; st.next_y = 0; }
     uint32_t used = 0, items = 0, vecs = 0;
     int      nt = 0;
     while (st.next_req < st.nreq && nt < kMaxReq) {
@@ -189,22 +222,9 @@ __device__ void plan_tiles(St &st) {
         const int shift = (int)((uintptr_t)(r.win + x0) & 15);
         const uint32_t need = tile_bytes(r, shift, w, h);
         if (need > kWinBytes - used) break; // flush what is planned; this tile opens the next round
-        Tile &t   = st.tile[nt];
-        t.req     = (uint8_t)st.next_req;
-        t.x0      = (int16_t)x0;
-        t.y0      = (int16_t)y0;
-        t.w       = (int16_t)w;
-        t.h       = (int16_t)h;
-        t.shift   = (uint16_t)shift;
-        t.pitch   = (uint16_t)(((shift + w - 1 + r.bw + 15) & ~15) + 16);
-        t.rows    = (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
-        t.lds_off = used;
-        t.ng      = (uint32_t)((shift & 3) + w + 3) >> 2;
-        t.narrow  = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
-        t.item0   = items;
-        t.nitems  = t.ng * (uint32_t)h * (t.narrow ? r.bh : 1u);
-        t.vec0    = vecs;
-        vecs += (uint32_t)(t.pitch >> 4) * t.rows;
+        Tile &t = st.tile[nt];
+        fill_tile(t, r, st.next_req, x0, y0, w, h, shift, used, items, vecs);
+        vecs += (uint32_t)(t.pitch >> 4) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
         items += t.nitems;
         used += need;
         nt++;
@@ -221,32 +241,33 @@ __device__ void plan_tiles(St &st) {
     st.ntile  = nt;
     st.nitems = (int)items;
     st.nvec   = (int)vecs;
+    st.last   = st.next_req >= st.nreq;
 }
 
 // wave 0: plan the next round in parallel -- lane i sizes pending request i as ONE tile; an inclusive scan of the byte
 // counts gives the arena offsets and how many leading requests fit.  Returns false (nothing planned) when the cursor is
 // inside a request or the first pending request does not fit the arena in one piece: lane 0 then runs plan_tiles().
-__device__ __forceinline__ bool plan_tiles_wave(St &st) {
+__device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
     const int lane = threadIdx.x;
-    if (st.next_x != 0 || st.next_y != 0) return false;
-    const int  idx  = st.next_req + lane;
-    const bool live = lane < kMaxReq && idx < st.nreq;
-    uint32_t need = 0, items = 0, vecs = 0, pitch = 0, rows = 0, ng = 0;
-    int      shift = 0, narrow = 0;
+    if (!first && (st.next_x != 0 || st.next_y != 0)) return false;
+    const int  nreq = st.nreq;
+    const int  idx  = (first ? 0 : st.next_req) + lane;
+    const bool live = lane < kMaxReq && idx < nreq;
+    uint32_t need = 0, items = 0, vecs = 0;
+    int      shift = 0;
     if (live) {
         const Req &r = st.req[idx];
-        shift  = (int)((uintptr_t)r.win & 15);
-        pitch  = (uint32_t)(((shift + r.sa_w - 1 + r.bw + 15) & ~15) + 16);
-        rows   = (uint32_t)(r.sa_h - 1 + (r.bh - 1) * r.rs + 1);
-        need   = pitch * rows;
-        ng     = (uint32_t)((shift & 3) + r.sa_w + 3) >> 2;
-        narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
-        items  = ng * (uint32_t)r.sa_h * (narrow ? r.bh : 1u);
-        vecs   = (pitch >> 4) * rows;
+        shift = (int)((uintptr_t)r.win & 15);
+        const uint32_t pitch = (uint32_t)(((shift + r.sa_w - 1 + r.bw + 15) & ~15) + 16);
+        const uint32_t rows  = (uint32_t)(r.sa_h - 1 + (r.bh - 1) * r.rs + 1);
+        const uint32_t ng    = (uint32_t)((shift & 3) + r.sa_w + 3) >> 2;
+        need  = pitch * rows;
+        items = ng * (uint32_t)r.sa_h * ((r.sa_w * r.sa_h <= kNarrowMaxPos) ? r.bh : 1u);
+        vecs  = (pitch >> 4) * rows;
     }
     uint32_t pb = need, pi = items, pv = vecs; // inclusive scans
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
+    for (int o = 1; o < kMaxReq; o <<= 1) {
         const uint32_t tb = __shfl_up(pb, o, 64), ti = __shfl_up(pi, o, 64), tv = __shfl_up(pv, o, 64);
         if (lane >= o) { pb += tb; pi += ti; pv += tv; }
     }
@@ -256,35 +277,35 @@ __device__ __forceinline__ bool plan_tiles_wave(St &st) {
     if (count == 0) return false;
     if (lane < count) {
         const Req &r = st.req[idx];
-        Tile &t   = st.tile[lane];
-        t.req     = (uint8_t)idx;
-        t.narrow  = (uint8_t)narrow;
-        t.x0 = 0; t.y0 = 0;
-        t.w       = r.sa_w;
-        t.h       = r.sa_h;
-        t.pitch   = (uint16_t)pitch;
-        t.shift   = (uint16_t)shift;
-        t.lds_off = pb - need;
-        t.rows    = rows;
-        t.item0   = pi - items;
-        t.nitems  = items;
-        t.ng      = ng;
-        t.vec0    = pv - vecs;
+        fill_tile(st.tile[lane], r, idx, 0, 0, r.sa_w, r.sa_h, shift, pb - need, pi - items, pv - vecs);
     }
     if (lane == count - 1) {
         st.ntile    = count;
         st.nitems   = (int)pi;
         st.nvec     = (int)pv;
         st.next_req = idx + 1;
+        st.next_x   = 0;
+        st.next_y   = 0;
+        st.last     = idx + 1 >= nreq;
     }
     return true;
 }
 
+// index of the tile that owns flattened element i, given each lane's tile start (lane j < ntile holds tile j's start)
+__device__ __forceinline__ int tile_of(uint32_t i, uint32_t my_start, int ntile) {
+    int ti = 0;
+    for (int j = 1; j < ntile; j++) ti += (i >= (uint32_t)__builtin_amdgcn_readlane((int)my_start, j)) ? 1 : 0;
+    return ti;
+}
+
 // all threads: copy the tiles' reference windows into the LDS arena with aligned 16-byte loads; the (tile, row, vector)
-// space is flattened so that every thread keeps four independent loads in flight
+// space is flattened so that every thread keeps four independent loads in flight.  Also clears the narrow accumulators.
 __device__ __forceinline__ void stage_tiles(Shared &sh) {
-    const St &st = sh.st;
-    const int nvec = st.nvec;
+    St       &st    = sh.st;
+    const int nvec  = st.nvec, ntile = st.ntile;
+    const int lane  = threadIdx.x & 63;
+    const uint32_t my_vec0 = lane < ntile ? st.tile[lane].vec0 : 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < ntile * kNarrowMaxPos; i += kThreads) st.sadbuf[i] = 0;
     for (int base = threadIdx.x; base < nvec; base += 4 * kThreads) {
         uint4 v[4];
         int   dst[4];
@@ -293,13 +314,10 @@ __device__ __forceinline__ void stage_tiles(Shared &sh) {
             const int i = base + u * kThreads;
             dst[u] = -1;
             if (i < nvec) {
-                int ti = 0;
-                while (ti + 1 < st.ntile && i >= (int)st.tile[ti + 1].vec0) ti++;
-                const Tile &t = st.tile[ti];
-                const Req  &r = st.req[t.req];
-                const int k = i - (int)t.vec0, vpr = t.pitch >> 4, row = k / vpr, c = k - row * vpr;
-                const uint8_t *g0 = r.win + t.x0 + (long long)t.y0 * r.stride - t.shift; // 16-byte aligned
-                v[u]   = *reinterpret_cast<const uint4 *>(g0 + (long long)row * r.stride + c * 16);
+                const Tile &t = st.tile[tile_of((uint32_t)i, my_vec0, ntile)];
+                const int k = i - (int)t.vec0, vpr = t.pitch >> 4;
+                const int row = (int)div_by_magic((uint32_t)k, t.vpr_magic), c = k - row * vpr;
+                v[u]   = *reinterpret_cast<const uint4 *>(t.g0 + (long long)row * t.stride + c * 16);
                 dst[u] = (int)t.lds_off + row * t.pitch + c * 16;
             }
         }
@@ -383,41 +401,33 @@ __device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, cons
 
 __device__ __forceinline__ void lds_min_u64(u64 *addr, u64 v) { atomicMin(addr, v); }
 
-// all threads: evaluate every tile of the current plan
-__device__ __forceinline__ void eval_tiles(Shared &sh PROF_PARAM) {
-    St &st = sh.st;
-    // zero the narrow accumulators
-    for (int ti = 0; ti < st.ntile; ti++) {
-        const Tile &t = st.tile[ti];
-        if (t.narrow)
-            for (int i = threadIdx.x; i < t.w * t.h; i += kThreads) st.sadbuf[ti * kNarrowMaxPos + i] = 0;
-    }
-    __syncthreads();
-    PROF(20);
-    int ti = 0, cur_req = -1;
+// all threads: evaluate every item of the current plan.  Wide tiles: a thread keeps the running best of the positions
+// it visits and folds it into the request's key; narrow tiles: one item per block row, summed into sadbuf.
+__device__ __forceinline__ void eval_items(Shared &sh) {
+    St       &st     = sh.st;
+    const int nitems = st.nitems, ntile = st.ntile;
+    const int lane   = threadIdx.x & 63;
+    const uint32_t my_item0 = lane < ntile ? st.tile[lane].item0 : 0xFFFFFFFFu;
+    int cur_req = -1;
     u64 cur_best = ~0ull;
-    for (int it = threadIdx.x; it < st.nitems; it += kThreads) {
-        while (it >= (int)(st.tile[ti].item0 + st.tile[ti].nitems)) ti++;
-        const Tile &t = st.tile[ti];
-        const Req  &r = st.req[t.req];
-        int         k = it - (int)t.item0;
-        int         slice = 0;
-        if (t.narrow) {
-            slice = k % r.bh;
-            k /= r.bh;
-        }
-        const int g = k % (int)t.ng, y = k / (int)t.ng;
-        const int ysearch = t.y0 + y;
-        if (r.skip_even && !(ysearch & 1)) continue;
+    for (int it = threadIdx.x; it < nitems; it += kThreads) {
+        const int   ti = tile_of((uint32_t)it, my_item0, ntile);
+        const Tile &t  = st.tile[ti];
+        uint32_t    k  = (uint32_t)it - t.item0;
+        const uint32_t q = div_by_magic(k, t.slice_magic);
+        const int   slice = (int)(k - q * t.slices);
+        const int   y = (int)div_by_magic(q, t.ng_magic), g = (int)q - y * (int)t.ng;
+        const int   ysearch = t.y0 + y;
+        if (t.skip_even && !(ysearch & 1)) continue;
         // the quad covers LDS columns col0 .. col0+3 of the tile's rows; tile-relative x = column - shift
         const int col0 = (t.shift & ~3) + 4 * g;
         const int xq   = col0 - t.shift;
         const uint8_t *wrow0 = &sh.win[t.lds_off + y * t.pitch + col0];
-        const uint8_t *src   = src_view(sh, r.level);
-        const int      sp    = (r.level == 2) ? 64 : (r.level == 1 ? 32 : 16);
+        const uint8_t *src   = src_view(sh, t.level);
+        const int      sp    = (t.level == 2) ? 64 : (t.level == 1 ? 32 : 16);
         uint32_t       s4[4];
         if (t.narrow) {
-            quad_sad(src, sp, wrow0, t.pitch, r.rs, r.bw, slice, slice + 1, s4);
+            quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice, slice + 1, s4);
             for (int i = 0; i < 4; i++) {
                 const int x = xq + i;
                 if (x >= 0 && x < t.w) atomicAdd(&st.sadbuf[ti * kNarrowMaxPos + y * t.w + x], s4[i]);
@@ -428,7 +438,7 @@ __device__ __forceinline__ void eval_tiles(Shared &sh PROF_PARAM) {
                 cur_req  = t.req;
                 cur_best = ~0ull;
             }
-            quad_sad(src, sp, wrow0, t.pitch, r.rs, r.bw, 0, r.bh, s4);
+            quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, 0, t.bh, s4);
             for (int i = 0; i < 4; i++) {
                 const int x = xq + i;
                 if (x >= 0 && x < t.w) {
@@ -439,48 +449,56 @@ __device__ __forceinline__ void eval_tiles(Shared &sh PROF_PARAM) {
         }
     }
     if (cur_best != ~0ull) lds_min_u64(&st.req_key[cur_req], cur_best);
-    PROF(21);
-    __syncthreads();
-    PROF(22);
-    for (int tj = 0; tj < st.ntile; tj++) {
-        const Tile &t = st.tile[tj];
-        if (!t.narrow) continue;
-        const Req &r = st.req[t.req];
-        for (int i = threadIdx.x; i < t.w * t.h; i += kThreads) {
-            const int y = i / t.w, x = i - y * t.w;
-            if (r.skip_even && !((t.y0 + y) & 1)) continue;
-            const u64 key = ((u64)st.sadbuf[tj * kNarrowMaxPos + i] << 32) | ((u64)(uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + x);
-            lds_min_u64(&st.req_key[t.req], key);
-        }
-    }
-    __syncthreads();
 }
 
-// all threads: run st.req[0 .. nreq) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x),
-// or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.
+// all threads: fold the narrow tiles' sums into their requests' keys -- 32 lanes per tile, one lane per position
+__device__ __forceinline__ void eval_keys(Shared &sh) {
+    St       &st    = sh.st;
+    const int ntile = st.ntile;
+    for (int i = threadIdx.x; i < ntile * kNarrowMaxPos; i += kThreads) {
+        const int   tj = i / kNarrowMaxPos, pos = i % kNarrowMaxPos;
+        const Tile &t  = st.tile[tj];
+        u64         key = ~0ull;
+        if (t.narrow && pos < t.w * t.h) {
+            const int y = (int)(((float)pos + 0.5f) * __frcp_rn((float)t.w)), x = pos - y * t.w; // exact: w, pos <= 32
+            if (!(t.skip_even && !((t.y0 + y) & 1))) key = ((u64)st.sadbuf[i] << 32) | ((u64)(uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + x);
+        }
+#pragma unroll
+        for (int o = kNarrowMaxPos / 2; o >= 1; o >>= 1) {
+            const u64 other = (u64)__shfl_xor((unsigned long long)key, o, 64);
+            key = other < key ? other : key;
+        }
+        if (pos == 0 && key != ~0ull) lds_min_u64(&st.req_key[t.req], key);
+    }
+}
+
+// all threads: run st.req[0 .. nreq) (nreq >= 1) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x),
+// or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.  The caller's barrier has published
+// the requests; on return every thread may read the keys.
 __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
     St &st = sh.st;
-    if (threadIdx.x == 0) {
-        st.next_req = 0; st.next_x = 0; st.next_y = 0;
-        for (int i = 0; i < st.nreq; i++) st.req_key[i] = (0xffffffull << 32) | 0xffffffffull;
-    }
-    __syncthreads();
-    for (;;) {
+    for (bool first = true;; first = false) {
         PROF(23);
         if (threadIdx.x < 64) { // wave 0 plans; the serial planner only handles requests that must be cut into tiles
-            const bool planned = plan_tiles_wave(st);
-            if (!planned && threadIdx.x == 0) plan_tiles(st);
+            if (first && (int)threadIdx.x < st.nreq) st.req_key[threadIdx.x] = (0xffffffull << 32) | 0xffffffffull;
+            const bool planned = plan_tiles_wave(st, first);
+            if (!planned && threadIdx.x == 0) plan_tiles(st, first);
         }
         __syncthreads();
         PROF(17);
-        if (st.ntile == 0) break; // uniform: read from LDS after the barrier
+        const bool last = st.last; // stable until the next round's plan, which starts after this round's final barrier
         stage_tiles(sh);
         __syncthreads();
         PROF(18);
-        eval_tiles(sh PROF_ARG);
+        eval_items(sh);
+        PROF(21);
+        __syncthreads();
+        PROF(22);
+        eval_keys(sh);
+        __syncthreads();
         PROF(19);
+        if (last) break;
     }
-    __syncthreads();
 }
 
 __device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t stride, int sa_w, int sa_h, int bw, int bh, int rs,
