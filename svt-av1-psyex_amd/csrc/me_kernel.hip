@@ -44,6 +44,7 @@ constexpr int kThreads  = SVT_HIP_ME_THREADS;
 constexpr int kWaves    = kThreads / 64;
 constexpr int kMaxReq   = 32;    // searches per batch (4 HME regions x 8 refs)
 constexpr int kWinBytes = SVT_HIP_ME_WIN_BYTES; // LDS window arena
+constexpr int kSrc64Pitch = 80, kSrc32Pitch = 48, kSrc16Pitch = 16; // LDS row pitches of the source views: block rows 2 apart land on different banks
 constexpr int kNarrowMaxPos = 32; // searches with at most this many positions are split by block row instead
 
 // z_to_raster, motion_estimation.c:2520-2531: n_idx (quad-tree order) -> raster-within-depth PU index
@@ -79,8 +80,9 @@ struct Tile { // a rectangle of a Req whose window fits the LDS arena (carries w
     uint16_t shift;        // position x0 sits at LDS byte `shift` of a row
     uint32_t item0, nitems, ng;
     uint32_t vec0;         // index of this tile's first 16-byte vector in the batch's flattened staging order
-    uint32_t slices;       // narrow: block rows per position (one item each), else 1
-    uint32_t ng_magic, slice_magic, vpr_magic; // magic_of(ng), magic_of(slices), magic_of(pitch / 16)
+    uint32_t slices;       // narrow: block rows per position (one item each, ordered slice-major so that the lanes of a
+                           // wave mostly work on different positions and rows 1 apart), else 1
+    uint32_t ng_magic, h_magic, vpr_magic; // magic_of(ng), magic_of(h), magic_of(pitch / 16)
 };
 
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
@@ -120,10 +122,12 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     Req      req[kMaxReq];
     u64      req_key[kMaxReq];
     Tile     tile[kMaxReq];
-    uint32_t sadbuf[kMaxReq * kNarrowMaxPos];
+    union { // never live together: batched SAD rounds / integer search
+        uint32_t sadbuf[kMaxReq * kNarrowMaxPos];
+        u64      wave_best[kWaves][85];
+    };
     int      nme, nprobe;
     MeReq    me[8], me_probe[8];
-    u64      wave_best[kWaves][85];
     uint32_t best_sad[2][4][85];
     uint32_t best_mv[2][4][85];
     uint32_t me_dist[85];
@@ -134,9 +138,9 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
 struct Shared {
     MeKernelParams params; // launch parameters, copied once per workgroup (uniform LDS reads afterwards)
     St      st;
-    uint8_t src64[64 * 64];
-    uint8_t src32[32 * 32];
-    uint8_t src16[16 * 16];
+    __attribute__((aligned(16))) uint8_t src64[64 * kSrc64Pitch];
+    __attribute__((aligned(16))) uint8_t src32[32 * kSrc32Pitch];
+    __attribute__((aligned(16))) uint8_t src16[16 * kSrc16Pitch];
     __attribute__((aligned(16))) uint8_t win[kWinBytes];
 };
 
@@ -174,10 +178,17 @@ __device__ __forceinline__ const uint8_t *plane_at(const DevPlane &pl, int x, in
 __device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d <= 1u ? 0u : 0xFFFFFFFFu / d + 1u; }
 __device__ __forceinline__ uint32_t div_by_magic(uint32_t k, uint32_t m) { return m ? __umulhi(k, m) : k; }
 
+// LDS row pitch of a staged window: room for the widest read of the last quad, and an odd multiple of 16 bytes so that
+// consecutive rows start 4 (mod 8) banks apart
+__device__ __forceinline__ uint32_t row_pitch(int shift, int w, int bw) {
+    uint32_t p = (uint32_t)(shift + w + bw + 3 + 15) & ~15u;
+    return (p & 16u) ? p : p + 16u;
+}
+
 // bytes of LDS a tile of w x h positions needs (worst-case 16-byte phase when shift < 0)
 __device__ __forceinline__ uint32_t tile_bytes(const Req &r, int shift, int w, int h) {
     const int sh = shift < 0 ? 15 : shift;
-    return (uint32_t)(((sh + w - 1 + r.bw + 15) & ~15) + 16) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
+    return row_pitch(sh, w, r.bw) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1) + 16u; // + slack for the last row's over-read
 }
 
 __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, int x0, int y0, int w, int h, int shift, uint32_t lds_off,
@@ -190,7 +201,7 @@ __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, in
     t.narrow    = (uint8_t)narrow;
     t.bw = r.bw; t.bh = r.bh; t.rs = r.rs; t.level = r.level; t.skip_even = r.skip_even; t.pad = 0;
     t.x0 = (int16_t)x0; t.y0 = (int16_t)y0; t.w = (int16_t)w; t.h = (int16_t)h;
-    t.pitch     = (uint16_t)(((shift + w - 1 + r.bw + 15) & ~15) + 16);
+    t.pitch     = (uint16_t)row_pitch(shift, w, r.bw);
     t.shift     = (uint16_t)shift;
     t.ng        = (uint32_t)((shift & 3) + w + 3) >> 2;
     t.slices    = narrow ? r.bh : 1u;
@@ -198,7 +209,7 @@ __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, in
     t.nitems    = t.ng * (uint32_t)h * t.slices;
     t.vec0      = vec0;
     t.ng_magic    = magic_of(t.ng);
-    t.slice_magic = magic_of(t.slices);
+    t.h_magic     = magic_of((uint32_t)h);
     t.vpr_magic   = magic_of((uint32_t)t.pitch >> 4);
 }
 
@@ -258,10 +269,10 @@ __device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
     if (live) {
         const Req &r = st.req[idx];
         shift = (int)((uintptr_t)r.win & 15);
-        const uint32_t pitch = (uint32_t)(((shift + r.sa_w - 1 + r.bw + 15) & ~15) + 16);
+        const uint32_t pitch = row_pitch(shift, r.sa_w, r.bw);
         const uint32_t rows  = (uint32_t)(r.sa_h - 1 + (r.bh - 1) * r.rs + 1);
         const uint32_t ng    = (uint32_t)((shift & 3) + r.sa_w + 3) >> 2;
-        need  = pitch * rows;
+        need  = pitch * rows + 16u;
         items = ng * (uint32_t)r.sa_h * ((r.sa_w * r.sa_h <= kNarrowMaxPos) ? r.bh : 1u);
         vecs  = (pitch >> 4) * rows;
     }
@@ -414,9 +425,9 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
         const int   ti = tile_of((uint32_t)it, my_item0, ntile);
         const Tile &t  = st.tile[ti];
         uint32_t    k  = (uint32_t)it - t.item0;
-        const uint32_t q = div_by_magic(k, t.slice_magic);
-        const int   slice = (int)(k - q * t.slices);
-        const int   y = (int)div_by_magic(q, t.ng_magic), g = (int)q - y * (int)t.ng;
+        const uint32_t q = div_by_magic(k, t.ng_magic);
+        const int   g = (int)(k - q * t.ng);
+        const int   slice = t.narrow ? (int)div_by_magic(q, t.h_magic) : 0, y = (int)q - slice * t.h;
         const int   ysearch = t.y0 + y;
         if (t.skip_even && !(ysearch & 1)) continue;
         // the quad covers LDS columns col0 .. col0+3 of the tile's rows; tile-relative x = column - shift
@@ -424,7 +435,7 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
         const int xq   = col0 - t.shift;
         const uint8_t *wrow0 = &sh.win[t.lds_off + y * t.pitch + col0];
         const uint8_t *src   = src_view(sh, t.level);
-        const int      sp    = (t.level == 2) ? 64 : (t.level == 1 ? 32 : 16);
+        const int      sp    = (t.level == 2) ? kSrc64Pitch : (t.level == 1 ? kSrc32Pitch : kSrc16Pitch);
         uint32_t       s4[4];
         if (t.narrow) {
             quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice, slice + 1, s4);
@@ -569,7 +580,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, const MeKernelParams
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int row = by * 8 + (k < nrow ? k * rstep : 0);
-        const uint32_t *sp = reinterpret_cast<const uint32_t *>(&sh.src64[row * 64 + bx * 8]);
+        const uint32_t *sp = reinterpret_cast<const uint32_t *>(&sh.src64[row * kSrc64Pitch + bx * 8]);
         s[k][0] = sp[0];
         s[k][1] = sp[1];
     }
@@ -803,16 +814,16 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             for (int i = tid; i < 64 * 4; i += kThreads) {
                 const int row = i >> 2, cc = i & 3;
                 uint4 v; memcpy(&v, plane_at(p.cur.lvl[2], ox + cc * 16, oy + row), 16);
-                *reinterpret_cast<uint4 *>(&sh.src64[row * 64 + cc * 16]) = v;
+                *reinterpret_cast<uint4 *>(&sh.src64[row * kSrc64Pitch + cc * 16]) = v;
             }
             for (int i = tid; i < 32 * 2; i += kThreads) {
                 const int row = i >> 1, cc = i & 1;
                 uint4 v; memcpy(&v, plane_at(p.cur.lvl[1], (ox >> 1) + cc * 16, (oy >> 1) + row), 16);
-                *reinterpret_cast<uint4 *>(&sh.src32[row * 32 + cc * 16]) = v;
+                *reinterpret_cast<uint4 *>(&sh.src32[row * kSrc32Pitch + cc * 16]) = v;
             }
             for (int i = tid; i < 16; i += kThreads) {
                 uint4 v; memcpy(&v, plane_at(p.cur.lvl[0], ox >> 2, (oy >> 2) + i), 16);
-                *reinterpret_cast<uint4 *>(&sh.src16[i * 16]) = v;
+                *reinterpret_cast<uint4 *>(&sh.src16[i * kSrc16Pitch]) = v;
             }
         }
         __syncthreads();
