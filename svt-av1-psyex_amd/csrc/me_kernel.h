@@ -29,9 +29,75 @@ struct DevPyramid {
     DevPlane lvl[3]; // 0 = sixteenth, 1 = quarter, 2 = full
 };
 
+// 32-bit mirrors of SvtHipMeConfig / SvtHipMePictureDesc (same field names): sub-dword fields cannot be fetched with
+// scalar loads on gfx950, so the launcher widens them once.  u8 / u16 fields become int32_t -- exactly the value C's
+// integer promotion gives them in an expression -- wider fields keep their type.
+struct DevSearchArea { int32_t width, height; };
+struct DevSearchAreaMinMax { DevSearchArea sa_min, sa_max; };
+
+#define SVT_ME_CFG_SMALL(X) X(hme_search_method) X(me_search_method) X(enable_hme_flag) X(enable_hme_level0_flag) \
+    X(enable_hme_level1_flag) X(enable_hme_level2_flag) X(num_hme_sa_w) X(num_hme_sa_h) X(prehme_enable) \
+    X(prehme_skip_search_line) X(prehme_l1_early_exit) X(enable_me_hme_ref_pruning) \
+    X(prune_ref_if_hme_sad_dev_bigger_than_th) X(prune_ref_if_me_sad_dev_bigger_than_th) X(zz_sad_pct) X(phme_sad_pct) \
+    X(enable_me_sr_adjustment) X(reduce_me_sr_based_on_mv_length_th) X(stationary_hme_sad_abs_th) \
+    X(stationary_me_sr_divisor) X(reduce_me_sr_based_on_hme_sad_abs_th) X(me_sr_divisor_for_low_hme_sad) \
+    X(distance_based_hme_resizing) X(me_8x8_var_enabled) X(mv_sa_adj_enabled) X(mv_sa_adj_nearest_ref_only) \
+    X(mv_sa_adj_mv_size_th) X(mv_sa_adj_sa_multiplier) X(prune_me_candidates_th) X(use_best_unipred_cand_only) \
+    X(reduce_hme_l0_sr_th_min) X(reduce_hme_l0_sr_th_max)
+#define SVT_ME_CFG_U32(X) X(zz_sad_th) X(phme_sad_th) X(me_sr_div4_th) X(me_sr_div2_th) X(me_sr_mult2_th) X(me_early_exit_th) \
+    X(me_safe_limit_zz_th) X(prev_me_stage_based_exit_th)
+#define SVT_ME_DESC_SMALL(X) X(aligned_width) X(aligned_height) X(num_of_list_to_search) X(temporal_layer_index) \
+    X(hierarchical_levels) X(is_ref) X(similar_brightness_refs) X(enable_me_8x8) X(enable_me_16x16) \
+    X(max_number_of_pus_per_sb) X(max_cand) X(max_refs) X(max_l0) X(input_resolution) X(only_l_bwd) X(gm_enabled) \
+    X(gm_use_distance_based_active_th) X(b64_row_start) X(b64_row_count)
+
+struct DevMeConfig {
+#define SVT_X(n) int32_t n;
+    SVT_ME_CFG_SMALL(SVT_X)
+#undef SVT_X
+#define SVT_X(n) uint32_t n;
+    SVT_ME_CFG_U32(SVT_X)
+#undef SVT_X
+    DevSearchAreaMinMax hme_l0_sa, me_sa, prehme_sa_cfg[2];
+    DevSearchArea       hme_l1_sa, hme_l2_sa;
+};
+
+struct DevMeDesc {
+    uint64_t picture_number;
+    uint64_t ref_picture_number[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS];
+#define SVT_X(n) int32_t n;
+    SVT_ME_DESC_SMALL(SVT_X)
+#undef SVT_X
+    int32_t num_of_ref_pic_to_search[SVT_HIP_MAX_LISTS];
+};
+
+#ifdef __cplusplus
+static inline DevSearchArea dev_sa(const SvtHipSearchArea &a) { DevSearchArea r = {a.width, a.height}; return r; }
+static inline DevSearchAreaMinMax dev_sa(const SvtHipSearchAreaMinMax &a) { DevSearchAreaMinMax r = {dev_sa(a.sa_min), dev_sa(a.sa_max)}; return r; }
+static inline void dev_me_config(DevMeConfig &o, const SvtHipMeConfig &c) {
+#define SVT_X(n) o.n = c.n;
+    SVT_ME_CFG_SMALL(SVT_X)
+    SVT_ME_CFG_U32(SVT_X)
+#undef SVT_X
+    o.hme_l0_sa = dev_sa(c.hme_l0_sa); o.me_sa = dev_sa(c.me_sa);
+    o.prehme_sa_cfg[0] = dev_sa(c.prehme_sa_cfg[0]); o.prehme_sa_cfg[1] = dev_sa(c.prehme_sa_cfg[1]);
+    o.hme_l1_sa = dev_sa(c.hme_l1_sa); o.hme_l2_sa = dev_sa(c.hme_l2_sa);
+}
+static inline void dev_me_desc(DevMeDesc &o, const SvtHipMePictureDesc &d) {
+    o.picture_number = d.picture_number;
+    for (int l = 0; l < SVT_HIP_MAX_LISTS; l++) {
+        o.num_of_ref_pic_to_search[l] = d.num_of_ref_pic_to_search[l];
+        for (int r = 0; r < SVT_HIP_MAX_REFS; r++) o.ref_picture_number[l][r] = d.ref_picture_number[l][r];
+    }
+#define SVT_X(n) o.n = d.n;
+    SVT_ME_DESC_SMALL(SVT_X)
+#undef SVT_X
+}
+#endif
+
 struct MeKernelParams {
-    SvtHipMeConfig      cfg;
-    SvtHipMePictureDesc desc;
+    DevMeConfig         cfg;
+    DevMeDesc           desc;
     DevPyramid          cur;
     DevPyramid          ref[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS];
     SvtHipMeResults     res;   // device pointers

@@ -60,6 +60,11 @@ __device__ const uint8_t c_16x16_to_32x32[16] = {1, 1, 2, 2, 1, 1, 2, 2, 3, 3, 4
 
 typedef unsigned long long u64;
 
+// Launch parameters live in the constant address space: uniform, read-only -> scalar loads, values in SGPRs
+#define SVT_CONST_AS __attribute__((address_space(4)))
+typedef const SVT_CONST_AS MeKernelParams CParams;
+typedef const SVT_CONST_AS DevPlane       CPlane;
+
 struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
     const uint8_t *win;   // reference sample of search index (0,0), block row 0
     uint32_t       stride;
@@ -136,7 +141,6 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
 };
 
 struct Shared {
-    MeKernelParams params; // launch parameters, copied once per workgroup (uniform LDS reads afterwards)
     St      st;
     __attribute__((aligned(16))) uint8_t src64[64 * kSrc64Pitch];
     __attribute__((aligned(16))) uint8_t src32[32 * kSrc32Pitch];
@@ -153,7 +157,7 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 // svt_aom_get_scaled_picture_distance, motion_estimation.c:1239-1243
 __device__ __forceinline__ uint32_t scaled_distance(uint32_t dist) { return (dist * 5) / 8 + ((dist % 8) ? 1 : 0); }
 
-__device__ __forceinline__ uint32_t ref_distance(const MeKernelParams &p, int li, int ri) {
+__device__ __forceinline__ uint32_t ref_distance(CParams &p, int li, int ri) {
     long long d = (long long)p.desc.picture_number - (long long)p.desc.ref_picture_number[li][ri];
     return (uint16_t)(int16_t)(d < 0 ? -d : d);
 }
@@ -166,7 +170,7 @@ __device__ __forceinline__ void clip_axis(int org, int &origin, int &size, int p
     if (org + origin + size > dim) size = imax(1, size - ((org + origin + size) - dim));
 }
 
-__device__ __forceinline__ const uint8_t *plane_at(const DevPlane &pl, int x, int y) {
+__device__ __forceinline__ const uint8_t *plane_at(CPlane &pl, int x, int y) {
     return pl.base + (long long)(pl.org_y + y) * pl.stride + (pl.org_x + x);
 }
 
@@ -527,7 +531,7 @@ __device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t st
 }
 
 // The svt_sad_loop_kernel call made by the HME levels and pre-HME (e.g. motion_estimation.c:891-909)
-__device__ __forceinline__ void push_hme_req(St &st, const MeKernelParams &p, int level, const DevPlane &rp, int org_x, int org_y,
+__device__ __forceinline__ void push_hme_req(St &st, CParams &p, int level, CPlane &rp, int org_x, int org_y,
                                              int bw, int bh, int ox, int oy, int sa_w, int sa_h, int skip) {
     const int full = (p.cfg.hme_search_method == 1);
     push_req(st, plane_at(rp, org_x + ox, org_y + oy), rp.stride, sa_w, sa_h, bw, full ? bh : (bh >> 1), full ? 1 : 2, level, skip);
@@ -568,7 +572,7 @@ __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
 
 // all threads: integer search for the refs in st.me[0..nme).  `merge` semantics follow the reference: strict
 // `<` against what is already in best_sad (initial MAX_SAD_VALUE, or the probe's result).
-__device__ __forceinline__ void run_me_searches(Shared &sh, const MeKernelParams &p, const MeReq *list, int count) {
+__device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count) {
     St       &st   = sh.st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub  = (p.cfg.me_search_method == 0);
@@ -664,9 +668,9 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, const MeKernelParams
 // lane-0 control logic (restates the scalar parts of motion_estimation.c; see per-function citations)
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ bool searched(const MeKernelParams &p, int li) { return p.desc.temporal_layer_index > 0 || li == 0; }
+__device__ __forceinline__ bool searched(CParams &p, int li) { return p.desc.temporal_layer_index > 0 || li == 0; }
 
-__device__ void set_hme_all(St &st, const MeKernelParams &p, int lvl, int li, int ri, int x, int y, uint32_t sad) {
+__device__ void set_hme_all(St &st, CParams &p, int lvl, int li, int ri, int x, int y, uint32_t sad) {
     for (int h = 0; h < p.cfg.num_hme_sa_h; h++)
         for (int w = 0; w < p.cfg.num_hme_sa_w; w++) {
             st.hx[lvl][li][ri][w][h] = (int16_t)x;
@@ -676,8 +680,8 @@ __device__ void set_hme_all(St &st, const MeKernelParams &p, int lvl, int li, in
 }
 
 // get_hme_l0_search_area, motion_estimation.c:1800-1868
-__device__ void hme_l0_search_area(St &st, const MeKernelParams &p, int li, int ri, uint32_t dist, int &sa_w, int &sa_h) {
-    const SvtHipMeConfig &c = p.cfg;
+__device__ void hme_l0_search_area(St &st, CParams &p, int li, int ri, uint32_t dist, int &sa_w, int &sa_h) {
+    auto &c = p.cfg;
     if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) {
         int is_hor = 1, is_ver = 1, is_still = 0;
         if (c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max && (li || ri)) {
@@ -705,7 +709,7 @@ __device__ void hme_l0_search_area(St &st, const MeKernelParams &p, int li, int 
 struct HmeGeom { int16_t ox, oy; };
 
 // hme_level_0/1/2 geometry (motion_estimation.c:820-1113): pushes the search and returns its origin
-__device__ HmeGeom push_hme_level(St &st, const MeKernelParams &p, int level, const DevPlane &rp, int org_x, int org_y, int bw, int bh,
+__device__ HmeGeom push_hme_level(St &st, CParams &p, int level, CPlane &rp, int org_x, int org_y, int bw, int bh,
                                   int sa_w, int sa_h, int cx, int cy, int sr_w, int sr_h) {
     sa_w = (int16_t)((sa_w + 7) & ~7);
     int pad_w, pad_h, ox, oy;
@@ -733,7 +737,7 @@ __device__ __forceinline__ void key_to_result(u64 key, int full, uint32_t &sad, 
 }
 
 // zero-MV style SAD request: svt_nxm_sad_kernel on every other row (get_zz_sad, motion_estimation.c:1667-1689)
-__device__ __forceinline__ void push_zz_req(St &st, const DevPlane &rp, int dx, int dy) {
+__device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy) {
     push_req(st, plane_at(rp, (int)st.org_x + dx, (int)st.org_y + dy), rp.stride, 1, 1, (int)st.b64_w, (int)st.b64_h >> 1, 2, 2, 0);
 }
 
@@ -748,13 +752,10 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &sh = *reinterpret_cast<Shared *>(smem_raw);
     St     &st = sh.st;
-    static_assert(sizeof(MeKernelParams) % 4 == 0, "params are copied as dwords");
-    for (int i = threadIdx.x; i < (int)(sizeof(MeKernelParams) / 4); i += kThreads)
-        reinterpret_cast<uint32_t *>(&sh.params)[i] = reinterpret_cast<const uint32_t *>(gparams)[i];
-    __syncthreads();
-    const MeKernelParams &p = sh.params;
-    const SvtHipMeConfig      &c = p.cfg;
-    const SvtHipMePictureDesc &d = p.desc;
+    // launch parameters: read-only, uniform addresses -> scalar loads through the constant cache, values in SGPRs
+    CParams &p = *(CParams *)gparams;
+    auto &c = p.cfg;
+    auto &d = p.desc;
     const int tid      = threadIdx.x;
     const int full_hme = (c.hme_search_method == 1);
     const int nl       = d.num_of_list_to_search;
@@ -794,7 +795,8 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             st.org_x = bxi * 64; st.org_y = byi * 64;
             st.b64_w = (uint32_t)(d.aligned_width - st.org_x) < 64 ? d.aligned_width - st.org_x : 64;
             st.b64_h = (uint32_t)(d.aligned_height - st.org_y) < 64 ? d.aligned_height - st.org_y : 64;
-            st.hme_l0_sa = c.hme_l0_sa;
+            st.hme_l0_sa.sa_min.width = (uint16_t)c.hme_l0_sa.sa_min.width; st.hme_l0_sa.sa_min.height = (uint16_t)c.hme_l0_sa.sa_min.height;
+            st.hme_l0_sa.sa_max.width = (uint16_t)c.hme_l0_sa.sa_max.width; st.hme_l0_sa.sa_max.height = (uint16_t)c.hme_l0_sa.sa_max.height;
             st.nreq = 0; st.nme = 0; st.nprobe = 0;
         }
         for (int i = tid; i < 3 * 2 * 4 * 2 * 2; i += kThreads) { (&st.hx[0][0][0][0][0])[i] = 0; (&st.hy[0][0][0][0][0])[i] = 0; (&st.hs[0][0][0][0][0])[i] = 0; }
@@ -891,7 +893,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             int sa_w = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.width * f), c.prehme_sa_cfg[sri].sa_max.width);
                             int sa_h = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.height * f), c.prehme_sa_cfg[sri].sa_max.height);
                             // prehme_core (:1568-1666)
-                            const DevPlane &rp = p.ref[li][ri].lvl[0];
+                            CPlane &rp = p.ref[li][ri].lvl[0];
                             const int ox16 = (int16_t)st.org_x >> 2, oy16 = (int16_t)st.org_y >> 2;
                             int ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
                             clip_axis(ox16, ox, sa_w, rp.org_x - 1, rp.width);
@@ -1136,7 +1138,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                         if (c.me_early_exit_th || !st.do_ref[li][ri]) continue;
                         int16_t cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
                         if ((cx != 0 || cy != 0) && d.is_ref) { // check_00_center (:1139-1206)
-                            const DevPlane &rp = p.ref[li][ri].lvl[2];
+                            CPlane &rp = p.ref[li][ri].lvl[2];
                             const int ox = (int16_t)st.org_x, oy = (int16_t)st.org_y;
                             if (ox + cx < -63) cx = (int16_t)(-63 - ox);
                             if (ox + cx > rp.width - 1) cx = (int16_t)(cx - ((ox + cx) - (rp.width - 1)));
@@ -1158,7 +1160,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                     for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
                         if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
                         if (!st.do_ref[li][ri]) continue;
-                        const DevPlane &rp = p.ref[li][ri].lvl[2];
+                        CPlane &rp = p.ref[li][ri].lvl[2];
                         int16_t  cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
                         const uint32_t dist = (uint16_t)scaled_distance(ref_distance(p, li, ri));
                         int16_t sa_w = (int16_t)imin((int)(c.me_sa.sa_min.width * dist), c.me_sa.sa_max.width);
@@ -1242,7 +1244,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             }
             if (run) {
                 __syncthreads();
-                PROF(3);
+                PROF(step == kMain ? 20 : 6 + step);
                 if (step < kProbe) {
                     if (st.nreq) run_searches(sh PROF_ARG); // uniform (LDS value read after the barrier)
                 } else {

@@ -93,8 +93,8 @@ int svt_hip_me_picture_async(SvtHipContext *ctx, const SvtHipMeConfig *cfg, cons
     if (rc) return rc;
     MeKernelParams p;
     memset(&p, 0, sizeof(p));
-    p.cfg  = *cfg;
-    p.desc = *desc;
+    dev_me_config(p.cfg, *cfg);
+    dev_me_desc(p.desc, *desc);
     p.cur  = cur->pyr;
     for (int li = 0; li < desc->num_of_list_to_search; li++)
         for (int ri = 0; ri < desc->num_of_ref_pic_to_search[li]; ri++) p.ref[li][ri] = refs[li][ri]->pyr;
