@@ -87,7 +87,7 @@ struct Tile { // a rectangle of a Req whose window fits the LDS arena (carries w
     uint32_t vec0;         // index of this tile's first 16-byte vector in the batch's flattened staging order
     uint32_t slices;       // narrow: block rows per position (one item each, ordered slice-major so that the lanes of a
                            // wave mostly work on different positions and rows 1 apart), else 1
-    uint32_t ng_magic, h_magic, vpr_magic; // magic_of(ng), magic_of(h), magic_of(pitch / 16)
+    float    ng_rcp, h_rcp, vpr_rcp; // rcp_of(ng), rcp_of(h), rcp_of(pitch / 16)
 };
 
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
@@ -136,6 +136,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     uint32_t best_sad[2][4][85];
     uint32_t best_mv[2][4][85];
     uint32_t me_dist[85];
+    uint8_t  cand0[88];  // candidate 0 of every PU (row order), for perform_gm_detection
     uint32_t red[8];
     int      job;
 };
@@ -149,6 +150,17 @@ struct Shared {
 };
 
 static_assert(sizeof(Shared) * SVT_HIP_ME_WG_PER_CU <= 160 * 1024, "the planned workgroups per CU must fit the 160 KiB LDS");
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += (u64)__shfl_xor((unsigned long long)v, o, 64);
+    return v;
+}
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -178,9 +190,10 @@ __device__ __forceinline__ const uint8_t *plane_at(CPlane &pl, int x, int y) {
 // Batched SAD searches
 // ---------------------------------------------------------------------------------------------
 
-// exact k / d for k, d < 65536 through one multiply: magic_of(d) = ceil(2^32 / d) (0 stands for d == 1)
-__device__ __forceinline__ uint32_t magic_of(uint32_t d) { return d <= 1u ? 0u : 0xFFFFFFFFu / d + 1u; }
-__device__ __forceinline__ uint32_t div_by_magic(uint32_t k, uint32_t m) { return m ? __umulhi(k, m) : k; }
+// exact k / d for k < 2^21 without an integer division: (k + 0.5) * rcp(d) is off by < 2^-22 relative, the fraction of
+// (k + 0.5) / d stays 0.5 / d away from the integers
+__device__ __forceinline__ float rcp_of(uint32_t d) { return __builtin_amdgcn_rcpf((float)d); }
+__device__ __forceinline__ uint32_t div_by_rcp(uint32_t k, float r) { return (uint32_t)(((float)k + 0.5f) * r); }
 
 // LDS row pitch of a staged window: room for the widest read of the last quad, and an odd multiple of 16 bytes so that
 // consecutive rows start 4 (mod 8) banks apart
@@ -212,9 +225,9 @@ __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, in
     t.item0     = item0;
     t.nitems    = t.ng * (uint32_t)h * t.slices;
     t.vec0      = vec0;
-    t.ng_magic    = magic_of(t.ng);
-    t.h_magic     = magic_of((uint32_t)h);
-    t.vpr_magic   = magic_of((uint32_t)t.pitch >> 4);
+    t.ng_rcp    = rcp_of(t.ng);
+    t.h_rcp     = rcp_of((uint32_t)h);
+    t.vpr_rcp   = rcp_of((uint32_t)t.pitch >> 4);
 }
 
 // lane 0: cut the pending requests into tiles whose reference windows fit the LDS arena.  Every request is
@@ -280,11 +293,12 @@ __device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
         items = ng * (uint32_t)r.sa_h * ((r.sa_w * r.sa_h <= kNarrowMaxPos) ? r.bh : 1u);
         vecs  = (pitch >> 4) * rows;
     }
-    uint32_t pb = need, pi = items, pv = vecs; // inclusive scans
-#pragma unroll
-    for (int o = 1; o < kMaxReq; o <<= 1) {
-        const uint32_t tb = __shfl_up(pb, o, 64), ti = __shfl_up(pi, o, 64), tv = __shfl_up(pv, o, 64);
-        if (lane >= o) { pb += tb; pi += ti; pv += tv; }
+    uint32_t pb = need, pi = items, pv = vecs; // inclusive scans: lane j's terms reach the lanes above it
+    const int npend = imin(nreq - (idx - lane), kMaxReq);
+    for (int j = 0; j + 1 < npend; j++) {
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)need, j), ti = (uint32_t)__builtin_amdgcn_readlane((int)items, j),
+                       tv = (uint32_t)__builtin_amdgcn_readlane((int)vecs, j);
+        if (lane > j) { pb += tb; pi += ti; pv += tv; }
     }
     const bool ok    = live && pb <= (uint32_t)kWinBytes;
     const u64  mask  = __ballot(ok);
@@ -331,7 +345,7 @@ __device__ __forceinline__ void stage_tiles(Shared &sh) {
             if (i < nvec) {
                 const Tile &t = st.tile[tile_of((uint32_t)i, my_vec0, ntile)];
                 const int k = i - (int)t.vec0, vpr = t.pitch >> 4;
-                const int row = (int)div_by_magic((uint32_t)k, t.vpr_magic), c = k - row * vpr;
+                const int row = (int)div_by_rcp((uint32_t)k, t.vpr_rcp), c = k - row * vpr;
                 v[u]   = *reinterpret_cast<const uint4 *>(t.g0 + (long long)row * t.stride + c * 16);
                 dst[u] = (int)t.lds_off + row * t.pitch + c * 16;
             }
@@ -429,9 +443,9 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
         const int   ti = tile_of((uint32_t)it, my_item0, ntile);
         const Tile &t  = st.tile[ti];
         uint32_t    k  = (uint32_t)it - t.item0;
-        const uint32_t q = div_by_magic(k, t.ng_magic);
+        const uint32_t q = div_by_rcp(k, t.ng_rcp);
         const int   g = (int)(k - q * t.ng);
-        const int   slice = t.narrow ? (int)div_by_magic(q, t.h_magic) : 0, y = (int)q - slice * t.h;
+        const int   slice = t.narrow ? (int)div_by_rcp(q, t.h_rcp) : 0, y = (int)q - slice * t.h;
         const int   ysearch = t.y0 + y;
         if (t.skip_even && !(ysearch & 1)) continue;
         // the quad covers LDS columns col0 .. col0+3 of the tile's rows; tile-relative x = column - shift
@@ -765,23 +779,24 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7;
     int queue_probe = 0; // only lane 0's copy is used
+    auto fetch_job = [&]() {
+        int job = -1;
+        while (queue_probe < SVT_HIP_ME_QUEUES) {
+            const int      q  = (int)((xcc + queue_probe) & 7);
+            const uint32_t lo = p.queue_begin[q], hi = p.queue_begin[q + 1];
+            if (lo < hi) {
+                const uint32_t k = atomicAdd(&p.queue_head[q], 1u);
+                if (lo + k < hi) { job = (int)(lo + k); break; }
+            }
+            queue_probe++;
+        }
+        return job;
+    };
     PROF_DECL;
 
     for (;;) {
-        // ---- fetch the next b64 job -----------------------------------------------------------------
-        if (tid == 0) {
-            int job = -1;
-            while (queue_probe < SVT_HIP_ME_QUEUES) {
-                const int      q  = (int)((xcc + queue_probe) & 7);
-                const uint32_t lo = p.queue_begin[q], hi = p.queue_begin[q + 1];
-                if (lo < hi) {
-                    const uint32_t k = atomicAdd(&p.queue_head[q], 1u);
-                    if (lo + k < hi) { job = (int)(lo + k); break; }
-                }
-                queue_probe++;
-            }
-            st.job = job;
-        }
+        // ---- fetch the next b64 job (fetching ahead was measured slower: it defeats the queues' load balancing) -------
+        if (tid == 0) st.job = fetch_job();
         __syncthreads();
         const int job = st.job;
         if (job < 0) break; // every wave of the workgroup takes this exit together
@@ -1201,18 +1216,16 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             }
         };
         auto main_pre = [&]() {
-            if (tid == 0) {
+            if (tid < 64) { // wave 0: the 8x8-SAD variance is a wave reduction, lane 0 keeps the result
                 const int pic_w = (int16_t)d.aligned_width, pic_h = (int16_t)d.aligned_height;
                 for (int i = 0; i < st.nme; i++) {
-                    MeReq &m = st.me[i];
+                    const MeReq m = st.me[i];
                     int16_t sa_w = m.sa_w, sa_h = m.sa_h;
                     const int cx = m.ox, cy = m.oy;
                     if (m.probe) { // :1391-1439 -- only one point was searched: 64x64 SAD == sum of the 8x8 SADs
-                        const uint32_t *b8 = &st.best_sad[m.li][m.ri][21];
-                        const uint32_t  mean = st.best_sad[m.li][m.ri][0] / 64;
-                        uint32_t ssq = 0;
-                        for (int k = 0; k < 64; k++) { const int32_t dd = (int32_t)b8[k] - (int32_t)mean; ssq += (uint32_t)(dd * dd); }
-                        const uint32_t var = ssq / 64;
+                        const uint32_t mean = st.best_sad[m.li][m.ri][0] / 64;
+                        const int32_t  dd   = (int32_t)st.best_sad[m.li][m.ri][21 + tid] - (int32_t)mean;
+                        const uint32_t var  = wave_sum((uint32_t)(dd * dd)) / 64;
                         if (var > c.me_sr_mult2_th) { sa_w = (int16_t)((imax(1, sa_w * 3 / 2) + 7) & ~7); sa_h = (int16_t)imax(1, sa_h * 3 / 2); }
                         if (var < c.me_sr_div4_th) { sa_w = (int16_t)((imax(1, sa_w >> 2) + 7) & ~7); sa_h = (int16_t)imax(3, imax(1, sa_h >> 2)); }
                         else if (var < c.me_sr_div2_th) { sa_w = (int16_t)((imin(sa_w, sa_w >> 1) + 7) & ~7); sa_h = (int16_t)imax(3, imin(sa_h, sa_h >> 1)); }
@@ -1221,7 +1234,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                     clip_axis((int16_t)st.org_x, ox, w, 63, pic_w);
                     w = (w < 8) ? w : (w & ~7);
                     clip_axis((int16_t)st.org_y, oy, h, 63, pic_h);
-                    m.ox = (int16_t)ox; m.oy = (int16_t)oy; m.sa_w = (int16_t)w; m.sa_h = (int16_t)h;
+                    if (tid == 0) { MeReq &o = st.me[i]; o.ox = (int16_t)ox; o.oy = (int16_t)oy; o.sa_w = (int16_t)w; o.sa_h = (int16_t)h; }
                 }
             }
         };
@@ -1283,14 +1296,14 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
 
         // ---- me_prune_ref (motion_estimation.c:1522-1565) ----------------------------------------------------
         if (c.enable_hme_flag && c.enable_me_hme_ref_pruning) {
+            for (int r = tid >> 6; r < 8; r += kWaves) { // one wave per reference: sum of its 64 8x8 SADs
+                const int li = r >> 2, ri = r & 3;
+                if (li >= nl || ri >= d.num_of_ref_pic_to_search[li]) continue;
+                const u64 t = st.do_ref[li][ri] ? (u64)wave_sum(st.best_sad[li][ri][21 + (tid & 63)]) : (u64)SVT_HIP_MAX_SAD_VALUE * 64;
+                if ((tid & 63) == 0) st.hme_sad64[li][ri] = t;
+            }
+            __syncthreads();
             if (tid == 0) {
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (!st.do_ref[li][ri]) { st.hme_sad64[li][ri] = (u64)SVT_HIP_MAX_SAD_VALUE * 64; continue; }
-                        u64 t = 0;
-                        for (int i = 0; i < 64; i++) t += st.best_sad[li][ri][21 + i];
-                        st.hme_sad64[li][ri] = t;
-                    }
                 const uint16_t th = c.prune_ref_if_me_sad_dev_bigger_than_th;
                 if (th != 0xFFFF) {
                     u64 best = ~0ull;
@@ -1314,19 +1327,26 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             auto pack   = [](unsigned dir, unsigned i0, unsigned i1, unsigned l0, unsigned l1) {
                 return (uint8_t)((dir & 3) | ((i0 & 3) << 2) | ((i1 & 3) << 4) | ((l0 & 1) << 6) | ((l1 & 1) << 7));
             };
-            // the reference writes these arrays only partially (malloc'ed): start every block from zero
-            for (int i = tid; i < (int)(n_pu * d.max_refs); i += kThreads) o_mv[i] = 0;
-            for (int i = tid; i < (int)(n_pu * d.max_cand); i += kThreads) o_cand[i] = 0;
-            for (int i = tid; i < (int)n_pu; i += kThreads) o_total[i] = 0;
-            __syncthreads();
+            // the reference writes these arrays only partially (malloc'ed): every row starts from zero.  A row is zeroed
+            // and filled by the one thread that owns it (same-address stores of a thread stay in order: no barrier)
+            auto zero_row = [&](int row) {
+                for (int k = 0; k < d.max_refs; k++) o_mv[row * d.max_refs + k] = 0;
+                for (int k = 0; k < d.max_cand; k++) o_cand[row * d.max_cand + k] = 0;
+                o_total[row] = 0;
+            };
+            for (int row = d.max_number_of_pus_per_sb + tid; row < (int)n_pu; row += kThreads) zero_row(row);
             for (int n = tid; n < d.max_number_of_pus_per_sb; n += kThreads) {
                 const int use = use_pu(n);
+                const int row = (n > 4) ? c_z_to_raster[n] : n; // == pu below (c_z_to_raster is the identity on 0..4)
+                if (row < (int)n_pu) zero_row(row); // PUs beyond n_pu (8x8 / 16x16 levels switched off) have no row and write nothing
+                uint8_t first = 0; // candidate 0 of this PU, kept for perform_gm_detection
+                auto put_cand = [&](int idx, uint8_t v) { o_cand[row * d.max_cand + idx] = v; if (idx == 0) first = v; };
                 uint32_t  nls = nl;
                 if (r0 == 1 && r1 == 0) { // construct_me_candidate_array_single_ref
                     const int pu   = c_z_to_raster[n];
                     st.me_dist[pu] = st.best_sad[0][0][n];
                     if (use) o_total[pu] = 1;
-                    if (st.do_ref[0][0] && use) { o_cand[pu * d.max_cand] = pack(0, 0, 0, 0, 0); o_mv[pu * d.max_refs] = st.best_mv[0][0][n]; }
+                    if (st.do_ref[0][0] && use) { put_cand(0, pack(0, 0, 0, 0, 0)); o_mv[pu * d.max_refs] = st.best_mv[0][0][n]; }
                 } else if (r0 == 1 && r1 == 1) { // construct_me_candidate_array_mrp_off
                     const int     pu = c_z_to_raster[n];
                     const uint8_t d0 = st.do_ref[0][0], d1 = (nls == 1) ? 0 : st.do_ref[1][0];
@@ -1351,12 +1371,12 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             continue;
                         }
                         if (use) {
-                            o_cand[pu * d.max_cand + off] = pack(li, 0, 0, li == 0 ? li : 24, li == 1 ? li : 24);
+                            put_cand(off, pack(li, 0, 0, li == 0 ? li : 24, li == 1 ? li : 24));
                             o_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
                         }
                         off++;
                     }
-                    if (blk[0] && blk[1] && use) { o_cand[pu * d.max_cand + off] = pack(2, 0, 0, 0, 1); o_total[pu] = (uint8_t)(off + 1); }
+                    if (blk[0] && blk[1] && use) { put_cand(off, pack(2, 0, 0, 0, 1)); o_total[pu] = (uint8_t)(off + 1); }
                 } else { // construct_me_candidate_array
                     const int pu = (n > 4) ? c_z_to_raster[n] : n;
                     uint8_t   off = 0;
@@ -1377,7 +1397,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                                 if (dev > best * prune_th) { blk[li][ri] = 0; continue; }
                             }
                             if (use) {
-                                o_cand[pu * d.max_cand + off] = pack(li, ri, ri, li == 0 ? li : 24, li == 1 ? li : 24);
+                                put_cand(off, pack(li, ri, ri, li == 0 ? li : 24, li == 1 ? li : 24));
                                 o_mv[pu * d.max_refs + (li ? d.max_l0 : 0) + ri] = st.best_mv[li][ri][n];
                             }
                             off++;
@@ -1386,29 +1406,31 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                         for (int a = 0; a < r0; a++)
                             for (int bb = 0; bb < r1; bb++) {
                                 if (d.only_l_bwd && (a > 0 || bb > 0)) continue;
-                                if (blk[0][a] && blk[1][bb]) o_cand[pu * d.max_cand + off++] = pack(2, a, bb, 0, 1);
+                                if (blk[0][a] && blk[1][bb]) put_cand(off++, pack(2, a, bb, 0, 1));
                             }
                         if (!d.only_l_bwd) {
                             for (int a = 1; a < r0; a++)
-                                if (blk[0][0] && blk[0][a]) o_cand[pu * d.max_cand + off++] = pack(2, 0, a, 0, 0);
-                            if (r1 == 3 && blk[1][0] && blk[1][2]) o_cand[pu * d.max_cand + off++] = pack(2, 0, 2, 1, 1);
+                                if (blk[0][0] && blk[0][a]) put_cand(off++, pack(2, 0, a, 0, 0));
+                            if (r1 == 3 && blk[1][0] && blk[1][2]) put_cand(off++, pack(2, 0, 2, 1, 1));
                         }
                     }
                     if (use) o_total[pu] = off;
                 }
+                if (row < 88) st.cand0[row] = first;
             }
             __syncthreads();
 
             PROF(14);
             // ---- compute_distortion (:2964-3008) + perform_gm_detection (:2838-2961) ---------------------------
-            if (tid == 0) {
-                uint32_t d32 = 0, d16 = 0, d8 = 0;
-                for (int i = 0; i < 4; i++) d32 += st.me_dist[1 + i];
-                for (int i = 0; i < 16; i++) d16 += st.me_dist[5 + i];
-                for (int i = 0; i < 64; i++) d8 += st.me_dist[21 + i];
-                const u64 mean = d8 / 64;
-                u64 ssq = 0;
-                for (int i = 0; i < 64; i++) { const long long dd = (long long)st.me_dist[21 + i] - (long long)mean; ssq += (u64)(dd * dd); }
+            if (tid < 64) { // wave 0: the sums are wave reductions, lane 0 writes
+                const uint32_t v8  = st.me_dist[21 + tid];
+                const uint32_t d8  = wave_sum(v8);
+                const uint32_t d16 = wave_sum(tid < 16 ? st.me_dist[5 + tid] : 0u);
+                const uint32_t d32 = wave_sum(tid < 4 ? st.me_dist[1 + tid] : 0u);
+                const u64       mean = d8 / 64;
+                const long long dd   = (long long)v8 - (long long)mean;
+                const u64       ssq  = wave_sum64((u64)(dd * dd));
+              if (tid == 0) {
                 const uint32_t pix = st.b64_w * st.b64_h;
                 p.res.me_8x8_cost_variance[b] = (uint32_t)(ssq / 64);
                 p.res.rc_me_distortion[b]     = d.input_resolution <= 2 ? d8 : d16;
@@ -1429,7 +1451,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             if (idx >= 21) idx = c_8x8_to_16x16[idx - 21];
                             if (!d.enable_me_16x16 && idx >= 5) idx = c_16x16_to_32x32[idx - 5];
                         } else if (!low && !d.enable_me_16x16 && idx >= 5) idx = c_16x16_to_32x32[idx - 5];
-                        const uint8_t  cb  = o_cand[idx * d.max_cand];
+                        const uint8_t  cb  = st.cand0[idx];
                         const unsigned dir = cb & 3;
                         const unsigned li  = (dir == 0 || dir == 2) ? ((cb >> 6) & 1) : ((cb >> 7) & 1);
                         const unsigned ri  = (dir == 0 || dir == 2) ? ((cb >> 2) & 3) : ((cb >> 4) & 3);
@@ -1451,6 +1473,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                 }
                 p.res.stationary_block_present_sb[b] = stationary;
                 p.res.rc_me_allow_gm[b]              = allow_gm;
+              }
             }
             PROF(15);
             // ---- optional search-level results ------------------------------------------------------------------
