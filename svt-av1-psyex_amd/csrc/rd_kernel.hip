@@ -325,17 +325,47 @@ struct RdParams {
 
 template <typename T> __device__ __forceinline__ int ldpix(const void *p, size_t i) { return (int)static_cast<const T *>(p)[i]; }
 
+// reductions over the LW lanes (a power of two) that work on one block
+template <int LW> __device__ __forceinline__ u64 seg_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = LW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int LW> __device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = LW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int LW> __device__ __forceinline__ uint32_t seg_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = LW / 2; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+
+__host__ __device__ constexpr int rd_lanes_per_block(int ts) { return tx_wide(ts) > tx_high(ts) ? tx_wide(ts) : tx_high(ts); }
+__host__ __device__ constexpr int rd_blocks_per_wave(int ts) { return 64 / rd_lanes_per_block(ts); }
+
+// =========================================================================================================
+// One wave64 per workgroup; the wave holds 64 / max(W, H) transform blocks side by side (lane = block * LW + l), so
+// the 1-D passes keep every lane busy for all sizes.  A block lives in ONE LDS array with row pitch W + 1 dwords:
+// column reads (stride 1) and row reads (stride W + 1) are both bank-conflict free.  The passes run in place --
+// a wave executes its LDS loads before the stores that follow them in program order -- and the packed
+// (top-left 32x32) coefficients of the 64-point sizes are compacted in place as well, which is what lets nine
+// 64x64 workgroups share a CU's LDS.
 // =========================================================================================================
 template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(const RdParams p) {
     constexpr int W = tx_wide(TS), H = tx_high(TS), WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
+    constexpr int LW = rd_lanes_per_block(TS), BPW = rd_blocks_per_wave(TS);
+    constexpr int PA = W + 1, PB = WP + 1; // row pitches (dwords) of the full block and of the packed coefficients
     constexpr int ROW_CLAMP = BD == 8 ? 16 : 18, COL_CLAMP = 16; // svt_av1_gen_inv_stage_range, inv_transforms.c:42-80
     constexpr bool RECT = (W == 2 * H || H == 2 * W);
     using Pix = typename std::conditional<BD == 8, uint8_t, uint16_t>::type;
-    __shared__ int32_t A[W * H], B[W * H];
-    const int          lane = threadIdx.x;
-    const uint32_t     job  = blockIdx.x;
-    if (job >= p.d.n_jobs) return;
-    const SvtHipTxJob jb = p.d.jobs[job];
+    __shared__ int32_t lds[BPW][H * PA];
+    const int      lane = threadIdx.x, blk = lane / LW, l = lane % LW;
+    const uint32_t job   = blockIdx.x * BPW + blk;
+    const bool     valid = job < p.d.n_jobs; // lanes of a missing block run along on job 0 and write nothing
+    int32_t *A = lds[blk];
+    const SvtHipTxJob jb = p.d.jobs[valid ? job : 0];
     const int tt = jb.tx_type & 15, vt = c_vtx[tt], ht = c_htx[tt];
     const bool ud = (vt == 2), lr = (ht == 2);
     const Pix *src  = static_cast<const Pix *>(p.d.src) + jb.src_offset;
@@ -344,29 +374,29 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
     const int bit_col = c_fwd_cos_col[ilog2c(W) - 2][ilog2c(H) - 2], bit_row = c_fwd_cos_row[ilog2c(W) - 2][ilog2c(H) - 2];
 
     // residual (svt_residual_kernel8bit / 16bit): int16 arithmetic as in the reference
-    for (int i = lane; i < W * H; i += 64) {
+    for (int i = l; i < W * H; i += LW) {
         const int r = i / W, c = i - r * W;
-        A[i] = (int16_t)((int16_t)src[(size_t)r * p.d.src_stride + c] - (int16_t)pred[(size_t)r * p.d.pred_stride + c]);
+        A[r * PA + c] = (int16_t)((int16_t)src[(size_t)r * p.d.src_stride + c] - (int16_t)pred[(size_t)r * p.d.pred_stride + c]);
     }
     __syncthreads();
     // forward columns (av1_tranform_two_d_core_c, transforms.c:2287-2308)
-    if (lane < W) {
+    if (l < W) {
         int32_t x[H];
 #pragma unroll
-        for (int r = 0; r < H; r++) x[r] = A[(ud ? H - 1 - r : r) * W + lane];
+        for (int r = 0; r < H; r++) x[r] = A[(ud ? H - 1 - r : r) * PA + l];
         shift_vec<H>(x, fsh[0]);
         fwd_1d<H>(x, vt, bit_col);
         shift_vec<H>(x, fsh[1]);
-        const int oc = lr ? W - 1 - lane : lane;
+        const int oc = lr ? W - 1 - l : l;
 #pragma unroll
-        for (int r = 0; r < H; r++) B[r * W + oc] = x[r];
+        for (int r = 0; r < H; r++) A[r * PA + oc] = x[r];
     }
     __syncthreads();
     // forward rows (:2310-2323)
-    if (lane < H) {
+    if (l < H) {
         int32_t x[W];
 #pragma unroll
-        for (int c = 0; c < W; c++) x[c] = B[lane * W + c];
+        for (int c = 0; c < W; c++) x[c] = A[l * PA + c];
         fwd_1d<W>(x, ht, bit_row);
         shift_vec<W>(x, fsh[2]);
         if constexpr (RECT) {
@@ -374,30 +404,34 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
             for (int c = 0; c < W; c++) x[c] = rshift64((i64)x[c] * 5793, 12);
         }
 #pragma unroll
-        for (int c = 0; c < W; c++) A[lane * W + c] = x[c];
+        for (int c = 0; c < W; c++) A[l * PA + c] = x[c];
     }
     __syncthreads();
     // 64-point sizes keep the top-left 32x32 (svt_handle_transform*_c, transforms.c:2374-2505)
     u64 tq = 0;
     if constexpr (W > 32 || H > 32) {
-        for (int i = lane; i < W * H; i += 64) {
+        for (int i = l; i < W * H; i += LW) {
             const int r = i / W, c = i - r * W;
-            if (r >= HP || c >= WP) tq += (u64)((i64)A[i] * A[i]);
+            if (r >= HP || c >= WP) { const int32_t v = A[r * PA + c]; tq += (u64)((i64)v * v); }
         }
-        tq = wave_sum_u64(tq);
+        tq = seg_sum_u64<LW>(tq);
+        __syncthreads(); // the compaction below overwrites discarded coefficients
     }
-    // SATD, quantize, coefficient-domain distortion over the kept NP coefficients (packed index rc = r*WP + c)
+    // SATD, quantize, coefficient-domain distortion over the kept NP coefficients (packed index rc = r*WP + c).  The
+    // dequantized value replaces the coefficient at the packed position r*PB + c <= r*PA + c: a later iteration never
+    // reads what an earlier one overwrote (its reads start beyond the earlier iteration's writes), and within one
+    // iteration the wave's loads precede its stores.
     const SvtHipQuantRow q = p.d.quant_rows[jb.quant_row];
     const int     log_scale = c_log_scale[TS];
     const int16_t *iscan    = p.iscan[(tt >= 10) ? ((tt & 1) ? 2 : 1) : 0];
     uint32_t satd = 0, eob = 0;
     u64      dres = 0, dpred = 0;
-    int32_t *co_out = p.d.coeff ? p.d.coeff + (size_t)job * NP : nullptr;
-    int32_t *q_out  = p.d.qcoeff ? p.d.qcoeff + (size_t)job * NP : nullptr;
-    int32_t *dq_out = p.d.dqcoeff ? p.d.dqcoeff + (size_t)job * NP : nullptr;
-    for (int rc = lane; rc < NP; rc += 64) {
+    int32_t *co_out = (p.d.coeff && valid) ? p.d.coeff + (size_t)job * NP : nullptr;
+    int32_t *q_out  = (p.d.qcoeff && valid) ? p.d.qcoeff + (size_t)job * NP : nullptr;
+    int32_t *dq_out = (p.d.dqcoeff && valid) ? p.d.dqcoeff + (size_t)job * NP : nullptr;
+    for (int rc = l; rc < NP; rc += LW) {
         const int r = rc / WP, c = rc - r * WP, ac = rc != 0;
-        const int32_t co = A[r * W + c], sign = co < 0 ? -1 : 0, a = (co ^ sign) - sign;
+        const int32_t co = A[r * PA + c], sign = co < 0 ? -1 : 0, a = (co ^ sign) - sign;
         satd += (uint32_t)a;
         int32_t qv = 0, dq = 0;
         if (p.d.quant_kind == 0) { // svt_aom_quantize_b_c_ii / svt_aom_highbd_quantize_b_c without a quantization matrix
@@ -423,53 +457,53 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
         const i64 dd = (i64)co - dqs;
         dres += (u64)(dd * dd);
         dpred += (u64)((i64)co * co);
-        B[rc] = dqs; // packed dequantized coefficients feed the inverse transform
+        A[r * PB + c] = dqs; // packed dequantized coefficients feed the inverse transform
         if (co_out) co_out[rc] = co;
         if (q_out) q_out[rc] = qs;
         if (dq_out) dq_out[rc] = dqs;
     }
-    satd  = wave_sum_u32(satd);
-    eob   = wave_max_u32(eob);
-    dres  = wave_sum_u64(dres);
-    dpred = wave_sum_u64(dpred);
+    satd  = seg_sum_u32<LW>(satd);
+    eob   = seg_max_u32<LW>(eob);
+    dres  = seg_sum_u64<LW>(dres);
+    dpred = seg_sum_u64<LW>(dpred);
     __syncthreads();
     // inverse rows (inv_txfm2d_add_c, inv_transforms.c:2497-2511): discarded frequencies are zero
-    if (lane < H) {
+    if (l < H) {
         int32_t x[W];
 #pragma unroll
         for (int c = 0; c < W; c++) {
-            int32_t v = (lane < HP && c < WP) ? B[lane * WP + c] : 0;
+            int32_t v = (l < HP && c < WP) ? A[l * PB + c] : 0;
             if constexpr (RECT) v = rshift64((i64)v * 2896, 12);
             x[c] = clampv(v, BD + 8);
         }
         inv_1d<W, ROW_CLAMP>(x, ht);
         shift_vec<W>(x, c_inv_shift0[TS]);
 #pragma unroll
-        for (int c = 0; c < W; c++) A[lane * W + c] = x[c];
+        for (int c = 0; c < W; c++) A[l * PA + c] = x[c];
     }
     __syncthreads();
     // inverse columns + reconstruction + SSE (:2513-2534; svt_spatial_full_distortion_kernel / 16-bit variant)
     u64 sse = 0;
-    if (lane < W) {
+    if (l < W) {
         int32_t x[H];
-        const int ic = lr ? W - 1 - lane : lane;
+        const int ic = lr ? W - 1 - l : l;
 #pragma unroll
-        for (int r = 0; r < H; r++) x[r] = clampv(A[r * W + ic], BD + 6 > 16 ? BD + 6 : 16);
+        for (int r = 0; r < H; r++) x[r] = clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16);
         inv_1d<H, COL_CLAMP>(x, vt);
         shift_vec<H>(x, -4);
-        Pix *rec = p.d.recon ? static_cast<Pix *>(p.d.recon) + jb.pred_offset : nullptr;
+        Pix *rec = (p.d.recon && valid) ? static_cast<Pix *>(p.d.recon) + jb.pred_offset : nullptr;
 #pragma unroll
         for (int r = 0; r < H; r++) {
             const int res = x[ud ? H - 1 - r : r];
-            int v = (int)pred[(size_t)r * p.d.pred_stride + lane] + res;
+            int v = (int)pred[(size_t)r * p.d.pred_stride + l] + res;
             v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
-            if (rec) rec[(size_t)r * p.d.pred_stride + lane] = (Pix)v;
-            const i64 e = (i64)src[(size_t)r * p.d.src_stride + lane] - v;
+            if (rec) rec[(size_t)r * p.d.pred_stride + l] = (Pix)v;
+            const i64 e = (i64)src[(size_t)r * p.d.src_stride + l] - v;
             sse += (u64)(e * e);
         }
     }
-    sse = wave_sum_u64(sse);
-    if (lane == 0) {
+    sse = seg_sum_u64<LW>(sse);
+    if (l == 0 && valid) {
         p.d.eob[job]  = (uint16_t)eob;
         p.d.satd[job] = satd;
         p.d.dist_coeff[2 * (size_t)job]     = dres;
@@ -480,8 +514,8 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
 }
 
 template <int BD> int launch_size(SvtHipContext *ctx, const RdParams &p) {
-    const dim3 g(p.d.n_jobs), b(64);
-#define CASE(S) case S: hipLaunchKernelGGL((rd_tx_kernel<S, BD>), g, b, 0, ctx->stream, p); break;
+    const dim3 b(64);
+#define CASE(S) case S: hipLaunchKernelGGL((rd_tx_kernel<S, BD>), dim3((p.d.n_jobs + rd_blocks_per_wave(S) - 1) / rd_blocks_per_wave(S)), b, 0, ctx->stream, p); break;
     switch (p.tx_size) {
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
     default: return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %d", p.tx_size);
