@@ -68,6 +68,38 @@ typedef struct SvtHipRdBatchDesc {
  * Returns non-zero (and leaves nothing enqueued) when the descriptor fails validation. */
 int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d);
 
+/* ---- batched block statistics ---------------------------------------------------------------------------------
+ * Per job: SAD, SSE, variance and Hadamard SATD of (src block - ref block).  Restates
+ *   svt_nxm_sad_kernel_helper_c / svt_aom_sad_16b_kernel_c          (C_DEFAULT/compute_sad_c.c:20-56,209)
+ *   svt_spatial_full_distortion_kernel_c / svt_full_distortion_kernel16_bits_c / svt_aom_sse_c
+ *                                                                   (C_DEFAULT/picture_operators_c.c:65-83, Codec/pic_operators.c:174-197)
+ *   svt_aom_variance{W}x{H}_c                                       (C_DEFAULT/variance.c:256-296)
+ *   hadamard_path_c = residual -> svt_aom_hadamard_NxN -> svt_aom_satd over <= 32x32 tiles
+ *                                                                   (Codec/enc_mode_config.c:2151-2217)                     */
+typedef struct SvtHipBlockJob {
+    uint32_t src_offset, ref_offset; /* sample offsets of the block's top-left sample in the two planes */
+    uint8_t  width, height;          /* 1..128 */
+    uint8_t  reserved[2];
+} SvtHipBlockJob;
+
+typedef struct SvtHipBlockStatsDesc {
+    uint8_t  bit_depth;   /* 8: planes are uint8; 10: planes are uint16 */
+    uint8_t  reserved[3];
+    uint32_t n_jobs;
+    uint32_t src_stride, ref_stride; /* in samples */
+    const void           *src, *ref; /* device pointers */
+    const SvtHipBlockJob *jobs;      /* device pointer, n_jobs entries */
+    /* per-job outputs, device pointers; any of them may be NULL (not computed) */
+    uint32_t *sad;      /* sum |src - ref| */
+    uint64_t *sse;      /* sum (src - ref)^2, 64-bit */
+    uint32_t *variance; /* sse32 - sum^2 / (w*h), the svt_aom_variance* return value (32-bit wrap like the reference) */
+    uint32_t *var_sse;  /* the `sse` out-parameter of svt_aom_variance* (32-bit) */
+    uint32_t *satd;     /* hadamard_path_c of a square block (4..128); 0 for other shapes; 8-bit planes only */
+} SvtHipBlockStatsDesc;
+
+/* Enqueues one batch on the context stream (asynchronous); one wave per job. */
+int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d);
+
 /* Full-pel motion-compensated prediction from ME results: every 16x16 PU copies the block of `ref` displaced by its
  * best integer MV (sb_best_mv = SvtHipMeResults.sb_best_mv, device pointer; list / ref_idx select the reference).
  * ref / pred are device planes of `bit_depth` 8 (uint8) or 10 (uint16), strides in samples, no padding needed

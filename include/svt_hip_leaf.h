@@ -1,0 +1,63 @@
+/*
+ * svt_hip_leaf.h -- pointer-level entries: the reference's kernel prototypes with a `_hip` suffix, to be installed
+ * by assignment into the rtcd function pointers (Source/Lib/Codec/aom_dsp_rtcd.h, common_dsp_rtcd.h) after
+ * svt_aom_setup_rtcd_internal (Globals/enc_handle.c:1444-1445).  Host pointers in, host results out, synchronous:
+ * every call stages its rows into device memory, launches, and copies the result back.  A validation / drop-in
+ * path -- one call is microseconds of CPU work but three PCIe round trips here; production goes through the batched
+ * entries (svt_hip_me_picture, svt_hip_rd_batch, svt_hip_block_stats_batch).
+ *
+ * The leaf kernels of the reference have no error channel and no context argument: bind a context once with
+ * svt_hip_leaf_bind(); a call without one, or a device failure inside one, aborts the process (no CPU fallback).
+ * Calls serialise on the bound context's stream (the symbols are reentrant through an internal lock).
+ */
+#ifndef SVT_HIP_LEAF_H
+#define SVT_HIP_LEAF_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "svt_hip_me.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int svt_hip_leaf_bind(SvtHipContext *ctx); /* NULL unbinds */
+
+/* svt_sad_loop_kernel (aom_dsp_rtcd.h:779; C_DEFAULT/compute_sad_c.c:58-101) */
+void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
+                             uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center,
+                             uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height);
+/* svt_nxm_sad_kernel_helper_c (compute_sad_c.c:209), svt_aom_sad_16b_kernel_c (:39-56) */
+uint32_t svt_nxm_sad_kernel_helper_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width);
+uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width);
+
+/* svt_aom_variance{W}x{H} (aom_dsp_rtcd.h:470-560; C_DEFAULT/variance.c:256-296) */
+unsigned int svt_aom_variance_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int width, int height, unsigned int *sse);
+#define SVT_HIP_DECL_VAR(W, H) unsigned int svt_aom_variance##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, unsigned int *sse);
+SVT_HIP_DECL_VAR(4, 4) SVT_HIP_DECL_VAR(4, 8) SVT_HIP_DECL_VAR(4, 16) SVT_HIP_DECL_VAR(8, 4) SVT_HIP_DECL_VAR(8, 8) SVT_HIP_DECL_VAR(8, 16)
+SVT_HIP_DECL_VAR(8, 32) SVT_HIP_DECL_VAR(16, 4) SVT_HIP_DECL_VAR(16, 8) SVT_HIP_DECL_VAR(16, 16) SVT_HIP_DECL_VAR(16, 32) SVT_HIP_DECL_VAR(16, 64)
+SVT_HIP_DECL_VAR(32, 8) SVT_HIP_DECL_VAR(32, 16) SVT_HIP_DECL_VAR(32, 32) SVT_HIP_DECL_VAR(32, 64) SVT_HIP_DECL_VAR(64, 16) SVT_HIP_DECL_VAR(64, 32)
+SVT_HIP_DECL_VAR(64, 64) SVT_HIP_DECL_VAR(64, 128) SVT_HIP_DECL_VAR(128, 64) SVT_HIP_DECL_VAR(128, 128)
+#undef SVT_HIP_DECL_VAR
+
+/* svt_aom_sse (aom_dsp_rtcd.h:53), svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (common_dsp_rtcd.h:164-168) */
+int64_t  svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height);
+uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
+                                                uint32_t recon_stride, uint32_t area_width, uint32_t area_height);
+uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
+                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height);
+
+/* svt_aom_hadamard_NxN (common_dsp_rtcd.h:1075-1085), svt_aom_satd (aom_dsp_rtcd.h:209) */
+void svt_aom_hadamard_4x4_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+void svt_aom_hadamard_8x8_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+void svt_aom_hadamard_16x16_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+void svt_aom_hadamard_32x32_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
+int  svt_aom_satd_hip(const int32_t *coeff, int length);
+/* hadamard_path_c (Codec/enc_mode_config.c:2151-2217) with the Buf2D arguments flattened: 8-bit input and prediction,
+ * square block of `block_size_wide` (4..128) */
+uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_LEAF_H */

@@ -88,13 +88,6 @@ def gen_sad_kernels():
     print("wrote sad_loop_kat", len(recs))
 
 
-if __name__ == "__main__":
-    os.makedirs(OUT, exist_ok=True)
-    assert pyoracle.ref_available(), "build oracle/_ref first (make -C oracle ref)"
-    gen_me()
-    gen_sad_kernels()
-
-
 def gen_presets():
     """Every (preset, resolution class, sc, rtc, layer, levels, qp, fps) -> the reference's MeContext controls."""
     import itertools
@@ -109,5 +102,58 @@ def gen_presets():
     print("wrote me_presets", len(keys))
 
 
+def gen_block_stats():
+    """Block statistics (SAD / SSE / variance / hadamard_path SATD) of the reference's `_c` kernels on two small planes."""
+    from svt_av1_psyex_amd import abi, stats
+    ref = pyoracle.load_ref()
+    P = C.c_void_p
+    ptr = lambda a: a.ctypes.data_as(P)
+    ref.svt_spatial_full_distortion_kernel_c.restype = C.c_uint64
+    ref.svt_full_distortion_kernel16_bits_c.restype = C.c_uint64
+    ref.ref_hadamard_path.restype = C.c_uint32
+    out = {}
+    for bd in (8, 10):
+        rng = np.random.default_rng(100 + bd)
+        W, H = 192, 160
+        dt = np.uint8 if bd == 8 else np.uint16
+        src = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+        refp = np.clip(src.astype(np.int32) + rng.integers(-24, 25, (H, W)), 0, (1 << bd) - 1).astype(dt)
+        src[:64, :64] = (1 << bd) - 1; refp[:64, :64] = 0          # extremes (VarianceTest.cc / SadTest.cc patterns)
+        src[64:128, :64] = 0; refp[64:128, :64] = (1 << bd) - 1
+        jobs = stats.random_jobs(rng, W, H, 160)
+        jobs[0] = (0, 0, 64, 64, (0, 0)); jobs[1] = (64 * W, 64 * W, 64, 64, (0, 0)); jobs[2] = (0, 64 * W, 32, 32, (0, 0))
+        exp = {name: np.zeros(len(jobs), dtype=d) for name, d in abi.STATS_OUT_FIELDS}
+        for j, jb in enumerate(jobs):
+            w, h = int(jb["width"]), int(jb["height"])
+            s = src.reshape(-1)[int(jb["src_offset"]):]
+            r = refp.reshape(-1)[int(jb["ref_offset"]):]
+            vs = C.c_uint32()
+            if bd == 8:
+                exp["sad"][j] = ref.svt_nxm_sad_kernel_helper_c(ptr(s), C.c_uint32(W), ptr(r), C.c_uint32(W), C.c_uint32(h), C.c_uint32(w))
+                exp["sse"][j] = ref.svt_spatial_full_distortion_kernel_c(ptr(s), C.c_uint32(0), C.c_uint32(W), ptr(r), C.c_int32(0), C.c_uint32(W), C.c_uint32(w), C.c_uint32(h))
+                if (w, h) in abi.VARIANCE_SIZES:
+                    exp["variance"][j] = getattr(ref, f"svt_aom_variance{w}x{h}_c")(ptr(s), W, ptr(r), W, C.byref(vs)) & 0xFFFFFFFF
+                else:  # no svt_aom_variance{W}x{H} of this shape: the generic 16-bit restatement on widened samples defines it
+                    s16, r16 = s.astype(np.uint16), r.astype(np.uint16)
+                    exp["variance"][j] = ref.svt_aom_variance_highbd_c(ptr(s16), W, ptr(r16), W, w, h, C.byref(vs)) & 0xFFFFFFFF
+                exp["var_sse"][j] = vs.value
+                if w == h:
+                    exp["satd"][j] = ref.ref_hadamard_path(ptr(s), C.c_uint32(W), ptr(r), C.c_uint32(W), C.c_uint32(w))
+            else:
+                exp["sad"][j] = ref.svt_aom_sad_16b_kernel_c(ptr(s), C.c_uint32(W), ptr(r), C.c_uint32(W), C.c_uint32(h), C.c_uint32(w))
+                exp["sse"][j] = ref.svt_full_distortion_kernel16_bits_c(ptr(s), C.c_uint32(0), C.c_uint32(W), ptr(r), C.c_int32(0), C.c_uint32(W), C.c_uint32(w), C.c_uint32(h))
+                exp["variance"][j] = ref.svt_aom_variance_highbd_c(ptr(s), W, ptr(r), W, w, h, C.byref(vs)) & 0xFFFFFFFF
+                exp["var_sse"][j] = vs.value
+        out.update({f"src{bd}": src, f"ref{bd}": refp, f"jobs{bd}": jobs.view(np.uint8).reshape(len(jobs), -1)})
+        out.update({f"{k}{bd}": v for k, v in exp.items()})
+    np.savez_compressed(os.path.join(OUT, "block_stats.npz"), **out)
+    print("wrote block_stats")
+
+
+GENERATORS = {"me": gen_me, "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats}
+
 if __name__ == "__main__":
-    gen_presets()
+    os.makedirs(OUT, exist_ok=True)
+    assert pyoracle.ref_available(), "build oracle/_ref first (make -C oracle ref)"
+    for name in (sys.argv[1:] or list(GENERATORS)):
+        GENERATORS[name]()

@@ -335,3 +335,28 @@ int ref_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
 }
 const int32_t *ref_cospi(int bit) { return cospi_arr(bit); }
 const int32_t *ref_sinpi(int bit) { return sinpi_arr(bit); }
+
+/* hadamard_path_c (Codec/enc_mode_config.c:2151-2217) on a square 8-bit block: fills the Buf2D arguments the way
+ * svt_aom_check_high_freq does (:2271-2300) and installs the `_c` kernels it dispatches through. */
+uint32_t ref_hadamard_path(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, uint32_t bsize_wide) {
+    static int16_t res[32 * 32];
+    static int32_t coeff[128 * 128];
+    svt_residual_kernel8bit = svt_residual_kernel8bit_c;
+
+    svt_aom_hadamard_8x8    = svt_aom_hadamard_8x8_c;
+    svt_aom_hadamard_16x16  = svt_aom_hadamard_16x16_c;
+    svt_aom_hadamard_32x32  = svt_aom_hadamard_32x32_c;
+    svt_aom_satd            = svt_aom_satd_c;
+    BlockSize bsize;
+    switch (bsize_wide) {
+    case 4: bsize = BLOCK_4X4; break;
+    case 8: bsize = BLOCK_8X8; break;
+    case 16: bsize = BLOCK_16X16; break;
+    case 32: bsize = BLOCK_32X32; break;
+    case 64: bsize = BLOCK_64X64; break;
+    default: bsize = BLOCK_128X128; break;
+    }
+    Buf2D r = {(uint8_t *)res, NULL, 0, 0, 32}, c = {(uint8_t *)coeff, NULL, 0, 0, (int)bsize_wide};
+    Buf2D i = {input, NULL, 0, 0, (int)input_stride}, p = {pred, NULL, 0, 0, (int)pred_stride};
+    return hadamard_path_c(r, c, i, p, bsize);
+}

@@ -137,3 +137,19 @@ TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
 JOB_DTYPE = [("src_offset", "<u4"), ("pred_offset", "<u4"), ("tx_type", "u1"), ("quant_row", "u1"), ("reserved", "u1", (2,))]
 QUANT_ROW_DTYPE = [(n, "<i2", (2,)) for n in ("zbin", "round", "quant", "quant_shift", "round_fp", "quant_fp", "dequant")]
 RD_OUT_FIELDS = [("eob", "<u2", 1), ("satd", "<u4", 1), ("dist_coeff", "<u8", 2), ("three_quad_energy", "<u8", 1), ("sse", "<u8", 1)]
+
+
+class BlockJob(C.Structure):
+    _fields_ = [("src_offset", C.c_uint32), ("ref_offset", C.c_uint32), ("width", C.c_uint8), ("height", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+class BlockStatsDesc(C.Structure):
+    _fields_ = [("bit_depth", C.c_uint8), ("reserved", C.c_uint8 * 3), ("n_jobs", C.c_uint32), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32),
+                ("src", C.c_void_p), ("ref", C.c_void_p), ("jobs", C.c_void_p),
+                ("sad", C.c_void_p), ("sse", C.c_void_p), ("variance", C.c_void_p), ("var_sse", C.c_void_p), ("satd", C.c_void_p)]
+
+
+BLOCK_JOB_DTYPE = [("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("reserved", "u1", (2,))]
+STATS_OUT_FIELDS = [("sad", "<u4"), ("sse", "<u8"), ("variance", "<u4"), ("var_sse", "<u4"), ("satd", "<u4")]
+VARIANCE_SIZES = [(4, 4), (4, 8), (4, 16), (8, 4), (8, 8), (8, 16), (8, 32), (16, 4), (16, 8), (16, 16), (16, 32), (16, 64), (32, 8), (32, 16),
+                  (32, 32), (32, 64), (64, 16), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128)]

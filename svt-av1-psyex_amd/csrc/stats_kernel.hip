@@ -1,0 +1,445 @@
+// stats_kernel.hip -- batched block statistics on gfx950: SAD, SSE, variance and Hadamard SATD of (source - reference)
+// blocks, plus the stand-alone exhaustive SAD search (svt_sad_loop_kernel) and Hadamard transforms behind the
+// pointer-level `_hip` entries of include/svt_hip_leaf.h.
+//
+// Reference functions restated (Source/Lib):
+//   svt_nxm_sad_kernel_helper_c / svt_aom_sad_16b_kernel_c          C_DEFAULT/compute_sad_c.c:20-56,209
+//   svt_sad_loop_kernel_c                                           C_DEFAULT/compute_sad_c.c:58-101
+//   svt_spatial_full_distortion_kernel_c / svt_full_distortion_kernel16_bits_c / svt_aom_sse_c / svt_aom_highbd_sse_c
+//                                                                   C_DEFAULT/picture_operators_c.c:65-83, Codec/pic_operators.c:174-197,
+//                                                                   Codec/enc_inter_prediction.c:559-583
+//   svt_aom_variance{W}x{H}_c / svt_aom_variance_highbd_c           C_DEFAULT/variance.c:256-296
+//   svt_aom_hadamard_{4x4,8x8,16x16,32x32}_c, svt_aom_satd_c        C_DEFAULT/picture_operators_c.c:176-326, Codec/common_dsp_rtcd.c:70-77
+//   hadamard_path_c                                                 Codec/enc_mode_config.c:2151-2217
+//
+// One wave64 per job.  Pixel statistics are lane-strided sums reduced across the wave; the Hadamard works on
+// <= 32x32 tiles staged in LDS with the reference's exact 16-bit / 32-bit intermediate widths and truncating shifts
+// (which is why this is butterfly code on the VALU and not an MFMA contraction: the shifts between the 8 / 16 / 32
+// stages are not linear, and 9-bit residuals do not fit the 8-bit integer MFMA operands).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include "svt_hip_internal.h"
+#include "../../include/svt_hip_dsp.h"
+#include "../../include/svt_hip_leaf.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef long long          i64;
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- Hadamard building blocks (same operation order and intermediate widths as the reference) -----------------
+__device__ __forceinline__ void had_col4(const int16_t *s, int st, int16_t *o) {
+    const int16_t b0 = (int16_t)((s[0] + s[st]) >> 1), b1 = (int16_t)((s[0] - s[st]) >> 1);
+    const int16_t b2 = (int16_t)((s[2 * st] + s[3 * st]) >> 1), b3 = (int16_t)((s[2 * st] - s[3 * st]) >> 1);
+    o[0] = (int16_t)(b0 + b2);
+    o[1] = (int16_t)(b1 + b3);
+    o[2] = (int16_t)(b0 - b2);
+    o[3] = (int16_t)(b1 - b3);
+}
+__device__ __forceinline__ void had_col8(const int16_t *s, int st, int16_t *o) {
+    int16_t b[8], c[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        b[2 * i]     = (int16_t)(s[2 * i * st] + s[(2 * i + 1) * st]);
+        b[2 * i + 1] = (int16_t)(s[2 * i * st] - s[(2 * i + 1) * st]);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        c[4 * g + 0] = (int16_t)(b[4 * g + 0] + b[4 * g + 2]);
+        c[4 * g + 1] = (int16_t)(b[4 * g + 1] + b[4 * g + 3]);
+        c[4 * g + 2] = (int16_t)(b[4 * g + 0] - b[4 * g + 2]);
+        c[4 * g + 3] = (int16_t)(b[4 * g + 1] - b[4 * g + 3]);
+    }
+    // output slots of c[i] + c[i+4] and c[i] - c[i+4]
+    o[0] = (int16_t)(c[0] + c[4]); o[2] = (int16_t)(c[0] - c[4]);
+    o[7] = (int16_t)(c[1] + c[5]); o[6] = (int16_t)(c[1] - c[5]);
+    o[3] = (int16_t)(c[2] + c[6]); o[1] = (int16_t)(c[2] - c[6]);
+    o[4] = (int16_t)(c[3] + c[7]); o[5] = (int16_t)(c[3] - c[7]);
+}
+
+constexpr int kResPitch = 34; // int16 row pitch of the residual tile in LDS (17 dwords: rows land on different banks)
+
+struct HadLds {
+    int16_t res[32 * kResPitch];
+    int16_t t[1024];
+    int32_t c[1024];
+};
+
+// Hadamard of the n x n residual tile in L.res (n = 4, 8, 16, 32); coefficients in L.c in the reference's order.
+// One wave; every step ends with a barrier.
+__device__ void hadamard_tile(HadLds &L, int n, int lane) {
+    if (n == 4) {
+        if (lane < 4) had_col4(L.res + lane, kResPitch, L.t + 4 * lane);
+        __syncthreads();
+        if (lane < 4) {
+            int16_t o[4];
+            had_col4(L.t + lane, 4, o);
+            for (int k = 0; k < 4; k++) L.c[4 * lane + k] = o[k];
+        }
+        __syncthreads();
+        return;
+    }
+    const int nb = n >> 3; // 8x8 sub-blocks per side
+    // coefficient base of the 8x8 sub-block at (by, bx): 16x16 blocks in raster order, 8x8 blocks in raster order inside
+    auto base_of = [&](int by, int bx) {
+        if (n == 8) return 0;
+        if (n == 16) return 64 * (2 * by + bx);
+        return 256 * (2 * (by >> 1) + (bx >> 1)) + 64 * (2 * (by & 1) + (bx & 1));
+    };
+    for (int it = lane; it < nb * nb * 8; it += 64) { // first pass: columns of every 8x8 sub-block
+        const int i = it & 7, sb = it >> 3, by = sb / nb, bx = sb - by * nb;
+        had_col8(L.res + (8 * by) * kResPitch + 8 * bx + i, kResPitch, L.t + base_of(by, bx) + 8 * i);
+    }
+    __syncthreads();
+    for (int it = lane; it < nb * nb * 8; it += 64) { // second pass: rows of the intermediate
+        const int i = it & 7, sb = it >> 3, by = sb / nb, bx = sb - by * nb;
+        const int base = base_of(by, bx);
+        int16_t   o[8];
+        had_col8(L.t + base + i, 8, o);
+        for (int k = 0; k < 8; k++) L.c[base + 8 * i + k] = o[k];
+    }
+    __syncthreads();
+    auto combine = [&](int32_t *c, int cn, int shift, int i) {
+        const int32_t a0 = c[i], a1 = c[cn + i], a2 = c[2 * cn + i], a3 = c[3 * cn + i];
+        const int32_t b0 = (a0 + a1) >> shift, b1 = (a0 - a1) >> shift, b2 = (a2 + a3) >> shift, b3 = (a2 - a3) >> shift;
+        c[i] = b0 + b2; c[cn + i] = b1 + b3; c[2 * cn + i] = b0 - b2; c[3 * cn + i] = b1 - b3;
+    };
+    if (n >= 16) {
+        const int n16 = (n == 16) ? 1 : 4;
+        for (int it = lane; it < n16 * 64; it += 64) combine(L.c + 256 * (it >> 6), 64, 1, it & 63);
+        __syncthreads();
+    }
+    if (n == 32) {
+        for (int it = lane; it < 256; it += 64) combine(L.c, 256, 2, it);
+        __syncthreads();
+    }
+}
+
+struct StatsParams {
+    SvtHipBlockStatsDesc d;
+};
+
+template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel(const StatsParams p) {
+    __shared__ HadLds L;
+    const int      lane = threadIdx.x;
+    const uint32_t job  = blockIdx.x;
+    const SvtHipBlockJob jb = p.d.jobs[job];
+    const int w = jb.width, h = jb.height;
+    const Pix *src = static_cast<const Pix *>(p.d.src) + jb.src_offset;
+    const Pix *ref = static_cast<const Pix *>(p.d.ref) + jb.ref_offset;
+    uint32_t sad = 0, sq32 = 0;
+    int32_t  sum = 0;
+    u64      sse = 0;
+    const float rw = __builtin_amdgcn_rcpf((float)w);
+    for (int i = lane; i < w * h; i += 64) {
+        const int r = (int)(((float)i + 0.5f) * rw), c = i - r * w; // exact for i < 2^21
+        const int d = (int)src[(size_t)r * p.d.src_stride + c] - (int)ref[(size_t)r * p.d.ref_stride + c];
+        sad += (uint32_t)(d < 0 ? -d : d);
+        sum += d;
+        sq32 += (uint32_t)(d * d);
+        sse += (u64)((i64)d * d);
+    }
+    sad  = wave_sum(sad);
+    sum  = wave_sum(sum);
+    sq32 = wave_sum(sq32);
+    sse  = wave_sum(sse);
+    if (lane == 0) {
+        if (p.d.sad) p.d.sad[job] = sad;
+        if (p.d.sse) p.d.sse[job] = sse;
+        if (p.d.var_sse) p.d.var_sse[job] = sq32;
+        if (p.d.variance) p.d.variance[job] = sq32 - (uint32_t)(((i64)sum * sum) / (w * h));
+    }
+    if (p.d.satd) { // hadamard_path_c: square blocks, <= 32x32 tiles
+        uint32_t satd = 0;
+        const int n = w < 32 ? w : 32;
+        if (w == h && (w == 4 || w == 8 || w == 16 || w == 32 || w == 64 || w == 128)) {
+            for (int ty = 0; ty < h; ty += n)
+                for (int tx = 0; tx < w; tx += n) {
+                    for (int i = lane; i < n * n; i += 64) {
+                        const int r = i / n, c = i - r * n;
+                        L.res[r * kResPitch + c] = (int16_t)((int16_t)src[(size_t)(ty + r) * p.d.src_stride + tx + c] -
+                                                             (int16_t)ref[(size_t)(ty + r) * p.d.ref_stride + tx + c]);
+                    }
+                    __syncthreads();
+                    hadamard_tile(L, n, lane);
+                    for (int i = lane; i < n * n; i += 64) { const int32_t v = L.c[i]; satd += (uint32_t)(v < 0 ? -v : v); }
+                    __syncthreads();
+                }
+        }
+        satd = wave_sum(satd);
+        if (lane == 0) p.d.satd[job] = satd;
+    }
+}
+
+// ---- svt_sad_loop_kernel: one thread per search position, first minimum in raster order through a 64-bit key ------
+struct SadLoopParams {
+    const uint8_t *src, *ref;
+    uint32_t       src_stride, ref_stride, block_height, block_width, src_stride_raw;
+    int            sa_w, sa_h, skip_even;
+    u64           *best; // initialised to (0xffffff << 32) | 0xffffffff
+};
+__global__ void __launch_bounds__(256) sad_loop_kernel(const SadLoopParams p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    u64       key = ~0ull;
+    if (idx < p.sa_w * p.sa_h) {
+        const int ys = idx / p.sa_w, xs = idx - ys * p.sa_w;
+        if (!(p.skip_even && !(ys & 1))) {
+            const uint8_t *r0 = p.ref + (size_t)ys * p.src_stride_raw + xs;
+            uint32_t       s  = 0;
+            for (uint32_t r = 0; r < p.block_height; r++)
+                for (uint32_t c = 0; c < p.block_width; c++) {
+                    const int d = (int)p.src[r * p.src_stride + c] - (int)r0[r * p.ref_stride + c];
+                    s += (uint32_t)(d < 0 ? -d : d);
+                }
+            key = ((u64)s << 32) | ((u64)(uint32_t)ys << 16) | (uint32_t)xs;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(key, o, 64); key = t < key ? t : key; }
+    if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(p.best, key);
+}
+
+// ---- stand-alone Hadamard (coefficients out) ------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) hadamard_kernel(const int16_t *src, int stride, int n, int32_t *coeff) {
+    __shared__ HadLds L;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n * n; i += 64) { const int r = i / n, c = i - r * n; L.res[r * kResPitch + c] = src[r * stride + c]; }
+    __syncthreads();
+    hadamard_tile(L, n, lane);
+    for (int i = lane; i < n * n; i += 64) coeff[i] = L.c[i];
+}
+
+__global__ void __launch_bounds__(64) satd_kernel(const int32_t *coeff, int n, int *out) {
+    int acc = 0;
+    for (int i = threadIdx.x; i < n; i += 64) { const int v = coeff[i]; acc += v < 0 ? -v : v; }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) *out = acc;
+}
+
+// ---- process-global context of the pointer-level entries -----------------------------------------------------------
+SvtHipContext *g_leaf_ctx = nullptr;
+std::mutex     g_leaf_mutex; // the reference calls its kernels from many threads; these entries serialise on one stream
+
+} // namespace
+
+extern "C" {
+
+int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d) {
+    if (!ctx || !d) return SVT_HIP_ERR_BAD_PARAM;
+    if (d->n_jobs == 0) return SVT_HIP_OK;
+    if (d->bit_depth != 8 && d->bit_depth != 10) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "bit_depth %u", d->bit_depth);
+    if (!d->src || !d->ref || !d->jobs) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the block-stats batch is null");
+    if (d->satd && d->bit_depth != 8) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "hadamard_path works on 8-bit input (enc_mode_config.c:2186)");
+    hipSetDevice(ctx->device);
+    StatsParams p;
+    p.d = *d;
+    if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_kernel<uint8_t>, dim3(d->n_jobs), dim3(64), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(block_stats_kernel<uint16_t>, dim3(d->n_jobs), dim3(64), 0, ctx->stream, p);
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+int svt_hip_leaf_bind(SvtHipContext *ctx) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    g_leaf_ctx = ctx;
+    return SVT_HIP_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Pointer-level entries: host pointers in, host results out, synchronous.  Each call stages the few rows it
+// needs into the context's scratch buffer, launches, and copies the result back -- a validation / drop-in path,
+// three PCIe round trips per call; production goes through the batched entries.  Without a bound context the
+// process aborts: there is no CPU fallback behind these symbols.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+SvtHipContext *leaf_ctx() {
+    if (!g_leaf_ctx) {
+        fprintf(stderr, "libsvthip: a _hip leaf kernel was called before svt_hip_leaf_bind(); there is no CPU fallback\n");
+        abort();
+    }
+    return g_leaf_ctx;
+}
+
+void leaf_check(SvtHipContext *ctx, hipError_t e, const char *what) {
+    if (e != hipSuccess) {
+        fprintf(stderr, "libsvthip: %s failed in a _hip leaf kernel: %s\n", what, hipGetErrorString(e));
+        (void)ctx;
+        abort(); // the reference's leaf kernels have no error channel
+    }
+}
+
+// device staging area: [0, bytes) carved by the caller
+uint8_t *leaf_scratch(SvtHipContext *ctx, size_t bytes) {
+    void *pp = nullptr;
+    if (svt_hip_scratch(ctx, bytes, &pp) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: out of device memory in a _hip leaf kernel\n"); abort(); }
+    return static_cast<uint8_t *>(pp);
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// copies `rows` rows of `row_bytes` bytes (host stride `stride_bytes`) to the device, packed with the same stride
+void upload_rows(SvtHipContext *ctx, void *dst, const void *src, size_t stride_bytes, size_t rows, size_t row_bytes) {
+    if (rows == 0) return;
+    leaf_check(ctx, hipMemcpyAsync(dst, src, (rows - 1) * stride_bytes + row_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+}
+
+struct StatsOut { uint32_t sad, variance, var_sse, satd; u64 sse; };
+
+// one (src, ref) block through block_stats_kernel
+StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t ref_stride, int w, int h, int bit_depth, bool want_satd) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    const size_t bpp = bit_depth == 8 ? 1 : 2;
+    const size_t sb = align256(((size_t)h - 1) * src_stride * bpp + (size_t)w * bpp), rb = align256(((size_t)h - 1) * ref_stride * bpp + (size_t)w * bpp);
+    uint8_t *base = leaf_scratch(ctx, sb + rb + 512);
+    uint8_t *d_src = base, *d_ref = base + sb, *d_job = d_ref + rb, *d_out = d_job + 256;
+    upload_rows(ctx, d_src, src, src_stride * bpp, h, (size_t)w * bpp);
+    upload_rows(ctx, d_ref, ref, ref_stride * bpp, h, (size_t)w * bpp);
+    SvtHipBlockJob job;
+    memset(&job, 0, sizeof(job));
+    job.width = (uint8_t)w; job.height = (uint8_t)h;
+    leaf_check(ctx, hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    SvtHipBlockStatsDesc d;
+    memset(&d, 0, sizeof(d));
+    d.bit_depth = (uint8_t)bit_depth; d.n_jobs = 1; d.src_stride = (uint32_t)src_stride; d.ref_stride = (uint32_t)ref_stride;
+    d.src = d_src; d.ref = d_ref; d.jobs = reinterpret_cast<const SvtHipBlockJob *>(d_job);
+    StatsOut *o = reinterpret_cast<StatsOut *>(d_out);
+    d.sad = &o->sad; d.variance = &o->variance; d.var_sse = &o->var_sse; d.sse = reinterpret_cast<uint64_t *>(&o->sse); d.satd = want_satd ? &o->satd : nullptr;
+    if (svt_hip_block_stats_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    StatsOut out;
+    memset(&out, 0, sizeof(out));
+    leaf_check(ctx, hipMemcpyAsync(&out, d_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return out;
+}
+
+} // namespace
+
+extern "C" {
+
+void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
+                             uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center,
+                             uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    *best_sad = 0xffffff;
+    if (search_area_width <= 0 || search_area_height <= 0 || block_height == 0 || block_width == 0) return;
+    const size_t sb = align256(((size_t)block_height - 1) * src_stride + block_width);
+    const size_t ref_rows_bytes = ((size_t)search_area_height - 1) * src_stride_raw + ((size_t)block_height - 1) * ref_stride + block_width + search_area_width - 1;
+    const size_t rb = align256(ref_rows_bytes);
+    uint8_t *base = leaf_scratch(ctx, sb + rb + 256);
+    uint8_t *d_src = base, *d_ref = base + sb;
+    u64     *d_best = reinterpret_cast<u64 *>(d_ref + rb);
+    leaf_check(ctx, hipMemcpyAsync(d_src, src, ((size_t)block_height - 1) * src_stride + block_width, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_ref, ref, ref_rows_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    const u64 init = (0xffffffull << 32) | 0xffffffffull;
+    leaf_check(ctx, hipMemcpyAsync(d_best, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    SadLoopParams p;
+    p.src = d_src; p.ref = d_ref; p.src_stride = src_stride; p.ref_stride = ref_stride; p.block_height = block_height; p.block_width = block_width;
+    p.src_stride_raw = src_stride_raw; p.sa_w = search_area_width; p.sa_h = search_area_height;
+    p.skip_even = (block_width == 16 && block_height <= 16 && skip_search_line) ? 1 : 0;
+    p.best = d_best;
+    const int npos = (int)search_area_width * (int)search_area_height;
+    hipLaunchKernelGGL(sad_loop_kernel, dim3((npos + 255) / 256), dim3(256), 0, ctx->stream, p);
+    leaf_check(ctx, hipGetLastError(), "sad_loop_kernel launch");
+    u64 best = 0;
+    leaf_check(ctx, hipMemcpyAsync(&best, d_best, sizeof(best), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if ((uint32_t)(best >> 32) < 0xffffff) { // strict `<` against the initial value, like the reference
+        *best_sad        = best >> 32;
+        *x_search_center = (int16_t)(best & 0xFFFF);
+        *y_search_center = (int16_t)((best >> 16) & 0xFFFF);
+    }
+}
+
+uint32_t svt_nxm_sad_kernel_helper_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
+    return leaf_stats(src, src_stride, ref, ref_stride, (int)width, (int)height, 8, false).sad;
+}
+
+uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
+    return leaf_stats(src, src_stride, ref, ref_stride, (int)width, (int)height, 10, false).sad;
+}
+
+unsigned int svt_aom_variance_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int width, int height, unsigned int *sse) {
+    const StatsOut o = leaf_stats(src, (size_t)src_stride, ref, (size_t)ref_stride, width, height, 8, false);
+    *sse = o.var_sse;
+    return o.variance;
+}
+
+#define SVT_HIP_VAR(W, H)                                                                                                             \
+    unsigned int svt_aom_variance##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, unsigned int *sse) { \
+        return svt_aom_variance_hip(src, src_stride, ref, ref_stride, W, H, sse);                                                       \
+    }
+SVT_HIP_VAR(4, 4) SVT_HIP_VAR(4, 8) SVT_HIP_VAR(4, 16) SVT_HIP_VAR(8, 4) SVT_HIP_VAR(8, 8) SVT_HIP_VAR(8, 16) SVT_HIP_VAR(8, 32)
+SVT_HIP_VAR(16, 4) SVT_HIP_VAR(16, 8) SVT_HIP_VAR(16, 16) SVT_HIP_VAR(16, 32) SVT_HIP_VAR(16, 64) SVT_HIP_VAR(32, 8) SVT_HIP_VAR(32, 16)
+SVT_HIP_VAR(32, 32) SVT_HIP_VAR(32, 64) SVT_HIP_VAR(64, 16) SVT_HIP_VAR(64, 32) SVT_HIP_VAR(64, 64) SVT_HIP_VAR(64, 128) SVT_HIP_VAR(128, 64)
+SVT_HIP_VAR(128, 128)
+#undef SVT_HIP_VAR
+
+int64_t svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height) {
+    return (int64_t)leaf_stats(a, (size_t)a_stride, b, (size_t)b_stride, width, height, 8, false).sse;
+}
+
+uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
+                                                uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
+    return leaf_stats(input + input_offset, input_stride, recon + recon_offset, recon_stride, (int)area_width, (int)area_height, 8, false).sse;
+}
+
+uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
+                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
+    return leaf_stats(reinterpret_cast<uint16_t *>(input) + input_offset, input_stride, reinterpret_cast<uint16_t *>(recon) + recon_offset, recon_stride,
+                      (int)area_width, (int)area_height, 10, false).sse;
+}
+
+uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide) {
+    return leaf_stats(input, input_stride, pred, pred_stride, (int)block_size_wide, (int)block_size_wide, 8, true).satd;
+}
+
+static void leaf_hadamard(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff, int n) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    const size_t sb = align256((((size_t)n - 1) * (size_t)src_stride + n) * 2);
+    uint8_t *base = leaf_scratch(ctx, sb + (size_t)n * n * 4);
+    leaf_check(ctx, hipMemcpyAsync(base, src_diff, (((size_t)n - 1) * (size_t)src_stride + n) * 2, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    hipLaunchKernelGGL(hadamard_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<const int16_t *>(base), (int)src_stride, n, reinterpret_cast<int32_t *>(base + sb));
+    leaf_check(ctx, hipGetLastError(), "hadamard_kernel launch");
+    leaf_check(ctx, hipMemcpyAsync(coeff, base + sb, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+void svt_aom_hadamard_4x4_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 4); }
+void svt_aom_hadamard_8x8_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 8); }
+void svt_aom_hadamard_16x16_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 16); }
+void svt_aom_hadamard_32x32_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 32); }
+
+int svt_aom_satd_hip(const int32_t *coeff, int length) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    if (length <= 0) return 0;
+    const size_t cb = align256((size_t)length * 4);
+    uint8_t *base = leaf_scratch(ctx, cb + 256);
+    leaf_check(ctx, hipMemcpyAsync(base, coeff, (size_t)length * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    hipLaunchKernelGGL(satd_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<const int32_t *>(base), length, reinterpret_cast<int *>(base + cb));
+    leaf_check(ctx, hipGetLastError(), "satd_kernel launch");
+    int out = 0;
+    leaf_check(ctx, hipMemcpyAsync(&out, base + cb, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return out;
+}
+
+} // extern "C"

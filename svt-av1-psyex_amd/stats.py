@@ -1,0 +1,65 @@
+"""Host-side helpers of the batched block-statistics entry (svt_hip_block_stats_batch) and its oracle counterpart."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False):
+    """n block jobs with AV1 block shapes at random positions inside a plane_w x plane_h plane."""
+    sizes = sizes or [(w, h) for w in (4, 8, 16, 32, 64, 128) for h in (4, 8, 16, 32, 64, 128) if max(w, h) <= 4 * min(w, h)]
+    if square_only:
+        sizes = [s for s in sizes if s[0] == s[1]]
+    jobs = np.zeros(n, dtype=abi.BLOCK_JOB_DTYPE)
+    for i in range(n):
+        w, h = sizes[rng.integers(len(sizes))]
+        w, h = min(w, plane_w), min(h, plane_h)
+        x0, y0 = rng.integers(0, plane_w - w + 1), rng.integers(0, plane_h - h + 1)
+        x1, y1 = rng.integers(0, plane_w - w + 1), rng.integers(0, plane_h - h + 1)
+        jobs[i] = (y0 * plane_w + x0, y1 * plane_w + x1, w, h, (0, 0))
+    return jobs
+
+
+def run_oracle(oracle, src, ref, jobs, bit_depth, satd=True):
+    """src / ref: 2-D numpy planes (uint8 or uint16); returns a dict of per-job arrays from oracle/stats_oracle.c"""
+    n = len(jobs)
+    out = {name: np.zeros(n, dtype=dt) for name, dt in abi.STATS_OUT_FIELDS}
+    d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
+    src, ref, jobs = np.ascontiguousarray(src), np.ascontiguousarray(ref), np.ascontiguousarray(jobs)
+    d.src, d.ref, d.jobs = src.ctypes.data, ref.ctypes.data, jobs.ctypes.data
+    for name, _ in abi.STATS_OUT_FIELDS:
+        if name == "satd" and not satd:
+            continue
+        setattr(d, name, out[name].ctypes.data)
+    oracle.orc_block_stats_batch.restype = C.c_int
+    rc = oracle.orc_block_stats_batch(C.byref(d))
+    assert rc == 0, rc
+    if not satd:
+        out.pop("satd")
+    return out
+
+
+def run_hip(ctx, src, ref, jobs, bit_depth, satd=True):
+    import torch
+    from . import api
+    L = api.lib()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+    n = len(jobs)
+    t_src, t_ref, t_jobs = dev(src), dev(ref), dev(jobs)
+    outs = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in abi.STATS_OUT_FIELDS}
+    d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
+    d.src, d.ref, d.jobs = t_src.data_ptr(), t_ref.data_ptr(), t_jobs.data_ptr()
+    for name, _ in abi.STATS_OUT_FIELDS:
+        if name == "satd" and not satd:
+            continue
+        setattr(d, name, outs[name].data_ptr())
+    torch.cuda.synchronize()
+    rc = L.svt_hip_block_stats_batch(ctx._h, C.byref(d))
+    if rc:
+        raise api.SvtHipError(f"svt_hip_block_stats_batch: {rc} {ctx.last_error()}")
+    ctx.sync()
+    res = {name: outs[name].cpu().numpy().view(dt) for name, dt in abi.STATS_OUT_FIELDS}
+    if not satd:
+        res.pop("satd")
+    return res

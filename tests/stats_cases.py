@@ -1,0 +1,28 @@
+"""Shared helpers of the block-statistics tests: the committed fixture (reference `_c` outputs) and its comparison."""
+import os
+
+import numpy as np
+
+from svt_av1_psyex_amd import abi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "block_stats.npz")
+
+
+def load_fixture(bd):
+    z = np.load(GOLDEN)
+    jobs = np.ascontiguousarray(z[f"jobs{bd}"]).view(abi.BLOCK_JOB_DTYPE).reshape(-1)
+    exp = {name: z[f"{name}{bd}"] for name, _ in abi.STATS_OUT_FIELDS}
+    return z[f"src{bd}"], z[f"ref{bd}"], jobs, exp
+
+
+def mismatches(exp, got, bd):
+    bad = []
+    for name, _ in abi.STATS_OUT_FIELDS:
+        if name == "satd" and bd != 8:
+            continue
+        if name not in got:
+            bad.append(f"{name}: missing")
+        elif not np.array_equal(exp[name], got[name]):
+            i = int(np.flatnonzero(exp[name] != got[name])[0])
+            bad.append(f"{name}: first mismatch at job {i}: {exp[name][i]} vs {got[name][i]}")
+    return bad

@@ -14,7 +14,7 @@ def declared_symbols():
     for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
         text = open(h).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        for m in re.finditer(r"\b(svt_hip_\w+)\s*\(", text):
+        for m in re.finditer(r"\b(svt_hip_\w+|svt_\w+_hip)\s*\(", text):
             # static inline helpers are not exported
             line_start = text.rfind("\n", 0, m.start())
             if "static inline" in text[line_start:m.start()]:
@@ -27,7 +27,10 @@ def test_library_exports_every_declared_symbol():
     L = api.lib()
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     assert not missing, f"declared in include/*.h but not exported by libsvthip.so: {missing}"
-    assert len(declared_symbols()) >= 15
+    assert len(declared_symbols()) >= 30
+    # the variance entries are declared through a macro
+    missing = [f"svt_aom_variance{w}x{h}_hip" for (w, h) in abi.VARIANCE_SIZES if not hasattr(L, f"svt_aom_variance{w}x{h}_hip")]
+    assert not missing, missing
 
 
 def test_struct_sizes_match_compiled_layout(oracle):

@@ -1,0 +1,125 @@
+"""GPU: the batched block statistics (svt_hip_block_stats_batch) and the pointer-level `_hip` leaf entries
+(include/svt_hip_leaf.h), through the C-ABI, against the reference fixtures and the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from stats_cases import load_fixture, mismatches
+from svt_av1_psyex_amd import abi, api, stats
+
+pytestmark = pytest.mark.gpu
+P = C.c_void_p
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def p(a):
+    return a.ctypes.data_as(P)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_batch_matches_reference_fixture(hip_ctx, bd):
+    src, ref, jobs, exp = load_fixture(bd)
+    got = stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=(bd == 8))
+    assert not mismatches(exp, got, bd)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_batch_matches_oracle_on_random_jobs(hip_ctx, oracle, bd):
+    rng = np.random.default_rng(40 + bd)
+    W, H = 640, 360
+    dt = np.uint8 if bd == 8 else np.uint16
+    src = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+    ref = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+    jobs = stats.random_jobs(rng, W, H, 3000)
+    odd = stats.random_jobs(rng, W, H, 64, sizes=[(12, 20), (1, 1), (3, 128), (128, 5), (24, 24), (100, 7)])  # not AV1 shapes: still defined
+    jobs = np.concatenate([jobs, odd])
+    a = stats.run_oracle(oracle, src, ref, jobs, bd, satd=(bd == 8))
+    b = stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=(bd == 8))
+    assert not mismatches(a, b, bd)
+
+
+def test_batch_rejects_bad_descriptors(hip_ctx):
+    L = api.lib()
+    d = abi.BlockStatsDesc(bit_depth=9, n_jobs=1)
+    assert L.svt_hip_block_stats_batch(hip_ctx._h, C.byref(d)) == 2
+    d = abi.BlockStatsDesc(bit_depth=8, n_jobs=1)  # null planes
+    assert L.svt_hip_block_stats_batch(hip_ctx._h, C.byref(d)) == 2
+    d = abi.BlockStatsDesc(bit_depth=8, n_jobs=0)
+    assert L.svt_hip_block_stats_batch(hip_ctx._h, C.byref(d)) == 0
+
+
+@pytest.fixture()
+def leaf(hip_ctx):
+    L = api.lib()
+    assert L.svt_hip_leaf_bind(hip_ctx._h) == 0
+    yield L
+    L.svt_hip_leaf_bind(None)
+
+
+def test_leaf_sad_loop_kernel_against_reference_kat(leaf):
+    """svt_sad_loop_kernel_hip on the reference's known answers (tests/golden/sad_loop_kat.npz)."""
+    z = np.load(os.path.join(GOLDEN, "sad_loop_kat.npz"))
+    so = ro = 0
+    for (bw, bh, sw, sh, skip, best, x, y), stride, rows in zip(z["meta"], z["ref_stride"], z["ref_rows"]):
+        src = np.ascontiguousarray(z["src"][so:so + bw * bh]); so += bw * bh
+        refp = np.ascontiguousarray(z["ref"][ro:ro + stride * rows]); ro += stride * rows
+        b, xs, ys = C.c_uint64(0), C.c_int16(-7), C.c_int16(-7)
+        leaf.svt_sad_loop_kernel_hip(p(src), C.c_uint32(int(bw)), p(refp), C.c_uint32(int(stride)), C.c_uint32(int(bh)), C.c_uint32(int(bw)),
+                                     C.byref(b), C.byref(xs), C.byref(ys), C.c_uint32(int(stride)), C.c_uint8(int(skip)), C.c_int16(int(sw)), C.c_int16(int(sh)))
+        assert (b.value, xs.value, ys.value) == (best, x, y), (bw, bh, sw, sh, skip)
+
+
+def test_leaf_sad_variance_sse(leaf, oracle):
+    rng = np.random.default_rng(9)
+    leaf.svt_aom_sse_hip.restype = C.c_int64
+    leaf.svt_spatial_full_distortion_kernel_hip.restype = C.c_uint64
+    leaf.svt_full_distortion_kernel16_bits_hip.restype = C.c_uint64
+    oracle.orc_spatial_sse8.restype = C.c_uint64
+    oracle.orc_spatial_sse16.restype = C.c_uint64
+    for (w, h) in abi.VARIANCE_SIZES:
+        a = rng.integers(0, 256, (h, w + 3)).astype(np.uint8); b = rng.integers(0, 256, (h, w + 8)).astype(np.uint8)
+        if (w + h) % 24 == 0:
+            a[:] = 255; b[:] = 0
+        s1, s2 = C.c_uint32(), C.c_uint32()
+        va = getattr(leaf, f"svt_aom_variance{w}x{h}_hip")(p(a), w + 3, p(b), w + 8, C.byref(s1))
+        vb = oracle.orc_variance8(p(a), w + 3, p(b), w + 8, w, h, C.byref(s2))
+        assert (va & 0xFFFFFFFF, s1.value) == (vb & 0xFFFFFFFF, s2.value), (w, h)
+        assert leaf.svt_nxm_sad_kernel_helper_hip(p(a), C.c_uint32(w + 3), p(b), C.c_uint32(w + 8), C.c_uint32(h), C.c_uint32(w)) == \
+            oracle.orc_nxm_sad(p(a), C.c_uint32(w + 3), p(b), C.c_uint32(w + 8), C.c_uint32(h), C.c_uint32(w))
+        assert leaf.svt_aom_sse_hip(p(a), w + 3, p(b), w + 8, w, h) == oracle.orc_spatial_sse8(p(a), C.c_uint32(0), C.c_uint32(w + 3), p(b), C.c_int32(0), C.c_uint32(w + 8), C.c_uint32(w), C.c_uint32(h))
+        assert leaf.svt_spatial_full_distortion_kernel_hip(p(a), C.c_uint32(1), C.c_uint32(w + 3), p(b), C.c_int32(2), C.c_uint32(w + 8), C.c_uint32(w - 2), C.c_uint32(h)) == \
+            oracle.orc_spatial_sse8(p(a), C.c_uint32(1), C.c_uint32(w + 3), p(b), C.c_int32(2), C.c_uint32(w + 8), C.c_uint32(w - 2), C.c_uint32(h))
+        a16 = rng.integers(0, 1024, (h, w + 3)).astype(np.uint16); b16 = rng.integers(0, 1024, (h, w + 8)).astype(np.uint16)
+        assert leaf.svt_full_distortion_kernel16_bits_hip(p(a16), C.c_uint32(1), C.c_uint32(w + 3), p(b16), C.c_int32(2), C.c_uint32(w + 8), C.c_uint32(w - 2), C.c_uint32(h)) == \
+            oracle.orc_spatial_sse16(p(a16), C.c_uint32(1), C.c_uint32(w + 3), p(b16), C.c_int32(2), C.c_uint32(w + 8), C.c_uint32(w - 2), C.c_uint32(h))
+        assert leaf.svt_aom_sad_16b_kernel_hip(p(a16), C.c_uint32(w + 3), p(b16), C.c_uint32(w + 8), C.c_uint32(h), C.c_uint32(w)) == \
+            oracle.orc_sad_16b(p(a16), C.c_uint32(w + 3), p(b16), C.c_uint32(w + 8), C.c_uint32(h), C.c_uint32(w))
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_leaf_hadamard_and_satd(leaf, oracle, n):
+    """hadamard_test.cc patterns: random 9-bit residuals, all-max, all-min; compared coefficient by coefficient."""
+    rng = np.random.default_rng(n)
+    for pat in ("random", "max", "min"):
+        res = rng.integers(-255, 256, (n, n + 3)).astype(np.int16)
+        if pat == "max":
+            res[:] = 255
+        if pat == "min":
+            res[:] = -255
+        a, b = np.zeros(n * n, np.int32), np.zeros(n * n, np.int32)
+        getattr(leaf, f"svt_aom_hadamard_{n}x{n}_hip")(p(res), C.c_ssize_t(n + 3), p(a))
+        getattr(oracle, f"orc_hadamard_{n}x{n}")(p(res), C.c_ssize_t(n + 3), p(b))
+        assert np.array_equal(a, b), (n, pat)
+        assert leaf.svt_aom_satd_hip(p(a), n * n) == oracle.orc_satd(p(b), n * n)
+
+
+def test_leaf_hadamard_path(leaf, oracle):
+    rng = np.random.default_rng(77)
+    leaf.svt_hip_hadamard_path.restype = C.c_uint32
+    oracle.orc_hadamard_path.restype = C.c_uint32
+    for n in (4, 8, 16, 32, 64, 128):
+        a = rng.integers(0, 256, (n, n + 5)).astype(np.uint8); b = rng.integers(0, 256, (n, n + 9)).astype(np.uint8)
+        assert leaf.svt_hip_hadamard_path(p(a), C.c_uint32(n + 5), p(b), C.c_uint32(n + 9), C.c_uint32(n)) == \
+            oracle.orc_hadamard_path(p(a), C.c_uint32(n + 5), p(b), C.c_uint32(n + 9), C.c_uint32(n))
