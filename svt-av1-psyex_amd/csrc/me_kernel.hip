@@ -335,24 +335,25 @@ __device__ __forceinline__ void stage_tiles(Shared &sh) {
     const int lane  = threadIdx.x & 63;
     const uint32_t my_vec0 = lane < ntile ? st.tile[lane].vec0 : 0xFFFFFFFFu;
     for (int i = threadIdx.x; i < ntile * kNarrowMaxPos; i += kThreads) st.sadbuf[i] = 0;
+    auto locate = [&](int i, const uint8_t *&g, int &dst) { // global source and LDS destination of flattened vector i
+        const Tile &t = st.tile[tile_of((uint32_t)i, my_vec0, ntile)];
+        const int k = i - (int)t.vec0, vpr = t.pitch >> 4;
+        const int row = (int)div_by_rcp((uint32_t)k, t.vpr_rcp), c = k - row * vpr;
+        g   = t.g0 + (long long)row * t.stride + c * 16;
+        dst = (int)t.lds_off + row * t.pitch + c * 16;
+    };
     for (int base = threadIdx.x; base < nvec; base += 4 * kThreads) {
-        uint4 v[4];
-        int   dst[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = base + u * kThreads;
-            dst[u] = -1;
-            if (i < nvec) {
-                const Tile &t = st.tile[tile_of((uint32_t)i, my_vec0, ntile)];
-                const int k = i - (int)t.vec0, vpr = t.pitch >> 4;
-                const int row = (int)div_by_rcp((uint32_t)k, t.vpr_rcp), c = k - row * vpr;
-                v[u]   = *reinterpret_cast<const uint4 *>(t.g0 + (long long)row * t.stride + c * 16);
-                dst[u] = (int)t.lds_off + row * t.pitch + c * 16;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (dst[u] >= 0) *reinterpret_cast<uint4 *>(&sh.win[dst[u]]) = v[u];
+        // out-of-range slots re-load the last vector (harmless) so that the four loads stay unconditional and in registers
+        const int i0 = base, i1 = imin(base + kThreads, nvec - 1), i2 = imin(base + 2 * kThreads, nvec - 1), i3 = imin(base + 3 * kThreads, nvec - 1);
+        const uint8_t *g0, *g1, *g2, *g3;
+        int            d0, d1, d2, d3;
+        locate(i0, g0, d0); locate(i1, g1, d1); locate(i2, g2, d2); locate(i3, g3, d3);
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(g0), v1 = *reinterpret_cast<const uint4 *>(g1);
+        const uint4 v2 = *reinterpret_cast<const uint4 *>(g2), v3 = *reinterpret_cast<const uint4 *>(g3);
+        *reinterpret_cast<uint4 *>(&sh.win[d0]) = v0;
+        *reinterpret_cast<uint4 *>(&sh.win[d1]) = v1;
+        *reinterpret_cast<uint4 *>(&sh.win[d2]) = v2;
+        *reinterpret_cast<uint4 *>(&sh.win[d3]) = v3;
     }
 }
 
@@ -1327,26 +1328,26 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
             auto pack   = [](unsigned dir, unsigned i0, unsigned i1, unsigned l0, unsigned l1) {
                 return (uint8_t)((dir & 3) | ((i0 & 3) << 2) | ((i1 & 3) << 4) | ((l0 & 1) << 6) | ((l1 & 1) << 7));
             };
-            // the reference writes these arrays only partially (malloc'ed): every row starts from zero.  A row is zeroed
-            // and filled by the one thread that owns it (same-address stores of a thread stay in order: no barrier)
-            auto zero_row = [&](int row) {
-                for (int k = 0; k < d.max_refs; k++) o_mv[row * d.max_refs + k] = 0;
-                for (int k = 0; k < d.max_cand; k++) o_cand[row * d.max_cand + k] = 0;
-                o_total[row] = 0;
-            };
-            for (int row = d.max_number_of_pus_per_sb + tid; row < (int)n_pu; row += kThreads) zero_row(row);
+            // The reference writes these arrays only partially (malloc'ed): every row starts from zero.  The block's rows
+            // are assembled in LDS (the window arena is idle here) and leave as coalesced stores.
+            uint32_t *l_mv    = reinterpret_cast<uint32_t *>(sh.win);
+            uint8_t  *l_cand  = sh.win + 4 * n_pu * d.max_refs;
+            uint8_t  *l_total = l_cand + n_pu * d.max_cand;
+            const int stage_dwords = (int)(4 * n_pu * d.max_refs + n_pu * d.max_cand + n_pu + 3) >> 2;
+            static_assert(kWinBytes >= 85 * (4 * SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS + 32 + 1), "the result rows of one block fit the arena");
+            for (int i = tid; i < stage_dwords; i += kThreads) reinterpret_cast<uint32_t *>(sh.win)[i] = 0;
+            __syncthreads();
             for (int n = tid; n < d.max_number_of_pus_per_sb; n += kThreads) {
                 const int use = use_pu(n);
                 const int row = (n > 4) ? c_z_to_raster[n] : n; // == pu below (c_z_to_raster is the identity on 0..4)
-                if (row < (int)n_pu) zero_row(row); // PUs beyond n_pu (8x8 / 16x16 levels switched off) have no row and write nothing
                 uint8_t first = 0; // candidate 0 of this PU, kept for perform_gm_detection
-                auto put_cand = [&](int idx, uint8_t v) { o_cand[row * d.max_cand + idx] = v; if (idx == 0) first = v; };
+                auto put_cand = [&](int idx, uint8_t v) { l_cand[row * d.max_cand + idx] = v; if (idx == 0) first = v; };
                 uint32_t  nls = nl;
                 if (r0 == 1 && r1 == 0) { // construct_me_candidate_array_single_ref
                     const int pu   = c_z_to_raster[n];
                     st.me_dist[pu] = st.best_sad[0][0][n];
-                    if (use) o_total[pu] = 1;
-                    if (st.do_ref[0][0] && use) { put_cand(0, pack(0, 0, 0, 0, 0)); o_mv[pu * d.max_refs] = st.best_mv[0][0][n]; }
+                    if (use) l_total[pu] = 1;
+                    if (st.do_ref[0][0] && use) { put_cand(0, pack(0, 0, 0, 0, 0)); l_mv[pu * d.max_refs] = st.best_mv[0][0][n]; }
                 } else if (r0 == 1 && r1 == 1) { // construct_me_candidate_array_mrp_off
                     const int     pu = c_z_to_raster[n];
                     const uint8_t d0 = st.do_ref[0][0], d1 = (nls == 1) ? 0 : st.do_ref[1][0];
@@ -1357,7 +1358,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                     const uint32_t s0 = st.best_sad[0][0][n], s1 = st.best_sad[1][0][n];
                     const uint32_t best = (d0 && d1) ? (s0 < s1 ? s0 : s1) : (d0 ? s0 : s1);
                     st.me_dist[pu] = best;
-                    if (use) o_total[pu] = 1;
+                    if (use) l_total[pu] = 1;
                     int min_list = -1;
                     if (c.use_best_unipred_cand_only && blk[0] && blk[1]) min_list = s0 < s1 ? 0 : 1;
                     for (uint32_t li = 0; li < nls && (use || off == 0); li++) {
@@ -1367,16 +1368,16 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             if (dev > best * prune_th) { blk[li] = 0; continue; }
                         }
                         if (min_list != -1 && min_list != (int)li) {
-                            if (use) o_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
+                            if (use) l_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
                             continue;
                         }
                         if (use) {
                             put_cand(off, pack(li, 0, 0, li == 0 ? li : 24, li == 1 ? li : 24));
-                            o_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
+                            l_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
                         }
                         off++;
                     }
-                    if (blk[0] && blk[1] && use) { put_cand(off, pack(2, 0, 0, 0, 1)); o_total[pu] = (uint8_t)(off + 1); }
+                    if (blk[0] && blk[1] && use) { put_cand(off, pack(2, 0, 0, 0, 1)); l_total[pu] = (uint8_t)(off + 1); }
                 } else { // construct_me_candidate_array
                     const int pu = (n > 4) ? c_z_to_raster[n] : n;
                     uint8_t   off = 0;
@@ -1398,7 +1399,7 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             }
                             if (use) {
                                 put_cand(off, pack(li, ri, ri, li == 0 ? li : 24, li == 1 ? li : 24));
-                                o_mv[pu * d.max_refs + (li ? d.max_l0 : 0) + ri] = st.best_mv[li][ri][n];
+                                l_mv[pu * d.max_refs + (li ? d.max_l0 : 0) + ri] = st.best_mv[li][ri][n];
                             }
                             off++;
                         }
@@ -1414,11 +1415,14 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
                             if (r1 == 3 && blk[1][0] && blk[1][2]) put_cand(off++, pack(2, 0, 2, 1, 1));
                         }
                     }
-                    if (use) o_total[pu] = off;
+                    if (use) l_total[pu] = off;
                 }
                 if (row < 88) st.cand0[row] = first;
             }
             __syncthreads();
+            for (int i = tid; i < (int)(n_pu * d.max_refs); i += kThreads) o_mv[i] = l_mv[i];
+            for (int i = tid; i < (int)(n_pu * d.max_cand); i += kThreads) o_cand[i] = l_cand[i];
+            for (int i = tid; i < (int)n_pu; i += kThreads) o_total[i] = l_total[i];
 
             PROF(14);
             // ---- compute_distortion (:2964-3008) + perform_gm_detection (:2838-2961) ---------------------------

@@ -45,6 +45,8 @@ int validate(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictur
     // capacity of MeSbResults rows as allocated by svt_aom_me_sb_results_ctor (pcs.c:91-117)
     const int r1     = d->num_of_list_to_search == 2 ? d->num_of_ref_pic_to_search[1] : 0;
     const int ncand  = (r[0] == 1 && r1 <= 1) ? (r1 ? 3 : 1) : r[0] + r1 + r[0] * r1 + (r[0] - 1) + (r1 == 3 ? 1 : 0);
+    if (d->max_cand > 32 || d->max_refs > SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS) // MAX_PA_ME_CAND is 23, MAX_PA_ME_MV 7 (me_sb_results.h:22-23)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "max_cand %u / max_refs %u exceed what one block's result rows may take", d->max_cand, d->max_refs);
     if (d->max_cand < ncand || d->max_l0 < r[0] || d->max_refs < d->max_l0 + r1 || d->max_refs < 1)
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "max_cand %u / max_refs %u / max_l0 %u too small for %d+%d references", d->max_cand,
                             d->max_refs, d->max_l0, r[0], r1);
