@@ -6,10 +6,12 @@ torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
 A *step* = one mini-GOP slice of 4 pictures of the sequence (reference distances 1, 2, 4, 8; temporal layers 4..1;
 R = 2 references per picture, one per list), each going through
-  1. open-loop ME for every 64x64 block (svt_hip_me_picture_async == N x svt_aom_motion_estimation_b64),
-  2. full-pel motion-compensated 10-bit prediction from the ME winners (svt_hip_fullpel_pred),
+  1. open-loop ME for every 64x64 block (== N x svt_aom_motion_estimation_b64); the four pictures of the step are in
+     flight together, as in the reference's ME threads, and share ONE launch (svt_hip_me_pictures_async),
+  2. full-pel motion-compensated 10-bit prediction from the ME winners (svt_hip_fullpel_pred, one launch per picture),
   3. the RD kernels on the 10-bit luma at three transform depths (64x64, 32x32, 16x16, DCT_DCT, "b" quantizer):
-     residual -> fwd txfm -> SATD -> quantize -> coeff distortion -> inv txfm -> SSE (svt_hip_rd_batch).
+     residual -> fwd txfm -> SATD -> quantize -> coeff distortion -> inv txfm -> SSE (svt_hip_rd_batch; one batch per
+     depth holds the blocks of all four pictures).
 With N GPUs the b64 rows of every picture are sharded across the ranks (all planes are replicated; no halo
 exchange) and the per-b64 ME results are all-gathered over RCCL once per step -- the exchange north_star names.
 `value` = luma pixels of the pictures fully processed per second, whole job (strong scaling: the pictures per step
@@ -73,9 +75,11 @@ class Workload:
         for pi, d in enumerate(DISTS):
             self.me_res[d] = self.layout.results_struct(self.me_buf.data_ptr(), pi, rank)
             self.mv_ptr[d] = self.me_res[d].sb_best_mv
-        # RD: prediction / recon planes and job lists restricted to this rank's rows
-        self.pred = torch.zeros(H * W, dtype=torch.int16, device="cuda")
-        self.recon = torch.zeros(H * W, dtype=torch.int16, device="cuda")
+        # RD: one prediction / recon plane per picture of the step (contiguous, so that one batch addresses all of them) and
+        # job lists restricted to this rank's rows
+        NP = len(DISTS)
+        self.pred = torch.zeros(NP * H * W, dtype=torch.int16, device="cuda")
+        self.recon = torch.zeros(NP * H * W, dtype=torch.int16, device="cuda")
         self.rows = torch.from_numpy(np.stack([rd.quant_row_from_step(140, 176)]).view(np.uint8).reshape(-1)).cuda()
         y_lo, y_hi = self.row0 * 64, min(self.row1 * 64, H)
         self.rd = []
@@ -84,7 +88,13 @@ class Workload:
             jobs = rd.grid_jobs(W, H, W, ts)
             ys = (jobs["src_offset"] // W).astype(np.int64)
             keep = (ys >= y_lo) & (ys < y_hi)  # bands are whole b64 rows, so a block never straddles two ranks
-            jobs = np.ascontiguousarray(jobs[keep])
+            one = np.ascontiguousarray(jobs[keep])
+            allp = []
+            for pi in range(NP):
+                j = one.copy()
+                j["pred_offset"] += pi * H * W  # picture pi's prediction / recon plane; the source picture is shared
+                allp.append(j)
+            jobs = np.concatenate(allp)
             n = len(jobs)
             t_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).cuda()
             outs = {name: torch.zeros(max(n, 1) * k * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt, k in abi.RD_OUT_FIELDS}
@@ -93,7 +103,8 @@ class Workload:
             for name, t in outs.items():
                 setattr(d, name, t.data_ptr())
             self.rd.append((ts, d, t_jobs, outs, n))
-            self.rd_pixels += n * abi.TX_W[ts] * abi.TX_H[ts]
+            self.rd_pixels += n * abi.TX_W[ts] * abi.TX_H[ts]  # per step (all pictures)
+        self.me_jobs = [(self.cfgs[d], self.descs[d], self.pics[CUR], self.refs(d), self.me_res[d]) for d in DISTS]
         torch.cuda.synchronize()
         log(f"[rank {rank}] setup {time.time() - t0:.1f}s: rows {self.row0}..{self.row1} of {self.h64}, RD jobs {[r[4] for r in self.rd]}")
 
@@ -103,21 +114,23 @@ class Workload:
     def step(self, ev=None):
         """Enqueue one step on the context stream.  `ev`: optional dict collecting (start, end) event pairs per kernel family."""
         L = api.lib()
-        for d in DISTS:
-            if ev is not None:
-                e0 = torch.cuda.Event(enable_timing=True); e0.record()
-            self.ctx.me_picture_async(self.cfgs[d], self.descs[d], self.pics[CUR], self.refs(d), self.me_res[d])
-            if ev is not None:
-                e1 = torch.cuda.Event(enable_timing=True); e1.record(); ev["me"].append((e0, e1))
+        mark = lambda: None
+        if ev is not None:
+            def mark():
+                e = torch.cuda.Event(enable_timing=True); e.record(); return e
+        e0 = mark()
+        self.ctx.me_pictures_async(self.me_jobs)
+        e1 = mark()
+        for pi, d in enumerate(DISTS):
             self.ctx.check(L.svt_hip_fullpel_pred(self.ctx._h, C.c_void_p(self.y10[CUR - d].data_ptr()), W, W, H, 10, C.c_void_p(self.mv_ptr[d]), 0, 0,
-                                                  self.row0, self.row1 - self.row0, C.c_void_p(self.pred.data_ptr()), W), "svt_hip_fullpel_pred")
-            if ev is not None:
-                e2 = torch.cuda.Event(enable_timing=True); e2.record(); ev["pred"].append((e1, e2))
-            for ts, desc, _, _, n in self.rd:
-                if n:
-                    self.ctx.check(L.svt_hip_rd_batch(self.ctx._h, C.byref(desc)), "svt_hip_rd_batch")
-            if ev is not None:
-                e3 = torch.cuda.Event(enable_timing=True); e3.record(); ev["rd"].append((e2, e3))
+                                                  self.row0, self.row1 - self.row0, C.c_void_p(self.pred.data_ptr() + 2 * pi * H * W), W), "svt_hip_fullpel_pred")
+        e2 = mark()
+        for ts, desc, _, _, n in self.rd:
+            if n:
+                self.ctx.check(L.svt_hip_rd_batch(self.ctx._h, C.byref(desc)), "svt_hip_rd_batch")
+        e3 = mark()
+        if ev is not None:
+            ev["me"].append((e0, e1)); ev["pred"].append((e1, e2)); ev["rd"].append((e2, e3))
 
 
 def cpu_baseline(wl, seconds_target=12.0):
@@ -235,8 +248,8 @@ def main():
     if rank == 0:
         R = 2
         frac_rows = (wl.row1 - wl.row0) / wl.h64
-        me_bytes = (1.3125 * (1 + R) + 0.166 * R) * W * H * frac_rows  # B_ME bytes per pixel
-        rd_bytes = wl.rd_pixels * (2 * 2 + 4 + 2)  # B_RD = 2*bpp + 4 (+bpp recon), bpp = 2
+        me_bytes = (1.3125 * (1 + R) + 0.166 * R) * W * H * frac_rows * len(DISTS)  # B_ME bytes per pixel x the 4 pictures of one launch
+        rd_bytes = wl.rd_pixels * (2 * 2 + 4 + 2)  # B_RD = 2*bpp + 4 (+bpp recon), bpp = 2; the step's three launches
         dom = "me" if kms["me"] >= kms["rd"] else "rd"
         ach = (me_bytes if dom == "me" else rd_bytes) / (kms[dom] * 1e-3) / 1e9
         out = {

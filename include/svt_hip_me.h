@@ -195,6 +195,19 @@ int svt_hip_me_picture_async(SvtHipContext *ctx, const SvtHipMeConfig *cfg, cons
                              const SvtHipPaPicture *const refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS],
                              const SvtHipMeResults *res_dev);
 
+/* Several pictures in ONE launch (the reference keeps several pictures in flight in its ME threads,
+ * me_process.c:140-172 picks them up segment by segment): the b64 jobs of all of them feed the same persistent
+ * workgroups, which matters when one picture -- or one GPU's row band of it -- has fewer blocks than the GPU has
+ * resident workgroups.  Every job is what one svt_hip_me_picture_async call takes; at most 16 per call. */
+typedef struct SvtHipMeJob {
+    const SvtHipMeConfig      *cfg;
+    const SvtHipMePictureDesc *desc;
+    const SvtHipPaPicture     *cur;
+    const SvtHipPaPicture     *refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS];
+    const SvtHipMeResults     *results; /* device pointers */
+} SvtHipMeJob;
+int svt_hip_me_pictures_async(SvtHipContext *ctx, uint32_t n_pictures, const SvtHipMeJob *jobs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,10 @@ class MeResults(C.Structure):
     ]
 
 
+class MeJob(C.Structure):
+    _fields_ = [("cfg", C.c_void_p), ("desc", C.c_void_p), ("cur", C.c_void_p), ("refs", (C.c_void_p * 4) * 2), ("results", C.c_void_p)]
+
+
 # (field, numpy dtype, per-b64 element count as a function of (n_pu, max_refs, max_cand))
 RESULT_FIELDS = [
     ("total_me_candidate_index", "u1", lambda n, r, c: n),

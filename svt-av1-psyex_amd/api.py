@@ -157,6 +157,17 @@ class Context:
         self.check(rc, "svt_hip_me_picture_async")
 
 
+    def me_pictures_async(self, jobs):
+        """Several pictures in one launch: `jobs` = [(cfg, desc, cur, refs, res_dev), ...] as for me_picture_async."""
+        arr = (abi.MeJob * len(jobs))()
+        for j, (cfg, desc, cur, refs, res) in zip(arr, jobs):
+            j.cfg, j.desc, j.results = C.addressof(cfg), C.addressof(desc), C.addressof(res)
+            j.cur = cur._h if isinstance(cur._h, int) else cur._h.value
+            for (li, ri), pic in refs.items():
+                j.refs[li][ri] = pic._h if isinstance(pic._h, int) else pic._h.value
+        self.check(lib().svt_hip_me_pictures_async(self._h, len(jobs), arr), "svt_hip_me_pictures_async")
+
+
 class DevicePicture:
     def __init__(self, ctx, handle, picture_number):
         self.ctx, self._h, self.picture_number = ctx, handle, picture_number

@@ -101,9 +101,21 @@ struct MeKernelParams {
     DevPyramid          cur;
     DevPyramid          ref[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS];
     SvtHipMeResults     res;   // device pointers
-    uint32_t            w64, row0, n_pu;
-    uint32_t            queue_begin[SVT_HIP_ME_QUEUES + 1]; // job index ranges (jobs are band-local b64 raster indices)
-    uint32_t           *queue_head;                         // SVT_HIP_ME_QUEUES counters, zeroed before launch
+    uint32_t            w64, row0, n_pu, pad;
 };
+
+// One launch covers the b64 jobs of up to SVT_HIP_ME_MAX_PICTURES pictures.  Global job index = job_base[pic] + the
+// picture's band-local b64 raster index; eight queues (one per XCD) each own a contiguous range of global indices.
+#define SVT_HIP_ME_MAX_PICTURES 16
+#define SVT_HIP_ME_HEADER_BYTES 256 /* sizeof(MeBatchHeader) rounded up: the parameter blocks follow at this offset */
+struct MeBatchHeader {
+    uint32_t  n_pictures, pad;
+    uint32_t  job_base[SVT_HIP_ME_MAX_PICTURES + 1];
+    uint32_t  queue_begin[SVT_HIP_ME_QUEUES + 1];
+    uint32_t *queue_head; // SVT_HIP_ME_QUEUES counters, zeroed before launch
+};
+#ifdef __cplusplus
+static_assert(sizeof(MeBatchHeader) <= SVT_HIP_ME_HEADER_BYTES, "header size");
+#endif
 
 #endif

@@ -19,6 +19,7 @@
 //     the parallel phases, on state kept in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "me_kernel.h"
 
 // Diagnostic build only (-DSVT_HIP_ME_PROFILE): lane 0 accumulates shader-clock deltas per phase (private array) and adds
@@ -763,17 +764,14 @@ __device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy) 
 // The kernel
 // =================================================================================================
 extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS, (SVT_HIP_ME_WG_PER_CU * (SVT_HIP_ME_THREADS / 64) + 3) / 4)
-svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
+svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     Shared &sh = *reinterpret_cast<Shared *>(smem_raw);
     St     &st = sh.st;
     // launch parameters: read-only, uniform addresses -> scalar loads through the constant cache, values in SGPRs
-    CParams &p = *(CParams *)gparams;
-    auto &c = p.cfg;
-    auto &d = p.desc;
-    const int tid      = threadIdx.x;
-    const int full_hme = (c.hme_search_method == 1);
-    const int nl       = d.num_of_list_to_search;
+    typedef const SVT_CONST_AS MeBatchHeader CHeader;
+    CHeader  &hdr = *(CHeader *)ghdr;
+    const int tid = threadIdx.x;
 
     // XCD-aware work pull: queue q holds a contiguous band of b64 rows; start with this XCD's own band
     uint32_t xcc = 0;
@@ -784,9 +782,9 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
         int job = -1;
         while (queue_probe < SVT_HIP_ME_QUEUES) {
             const int      q  = (int)((xcc + queue_probe) & 7);
-            const uint32_t lo = p.queue_begin[q], hi = p.queue_begin[q + 1];
+            const uint32_t lo = hdr.queue_begin[q], hi = hdr.queue_begin[q + 1];
             if (lo < hi) {
-                const uint32_t k = atomicAdd(&p.queue_head[q], 1u);
+                const uint32_t k = atomicAdd(&hdr.queue_head[q], 1u);
                 if (lo + k < hi) { job = (int)(lo + k); break; }
             }
             queue_probe++;
@@ -799,9 +797,19 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
         // ---- fetch the next b64 job (fetching ahead was measured slower: it defeats the queues' load balancing) -------
         if (tid == 0) st.job = fetch_job();
         __syncthreads();
-        const int job = st.job;
-        if (job < 0) break; // every wave of the workgroup takes this exit together
+        const int gjob = st.job;
+        if (gjob < 0) break; // every wave of the workgroup takes this exit together
         PROF(0);
+        // picture of this job (uniform): its parameter block is read with scalar loads
+        int pic = 0;
+        while (pic + 1 < (int)hdr.n_pictures && (uint32_t)gjob >= hdr.job_base[pic + 1]) pic++;
+        pic = __builtin_amdgcn_readfirstlane(pic);
+        CParams &p = ((CParams *)gparams)[pic];
+        auto &c = p.cfg;
+        auto &d = p.desc;
+        const int full_hme = (c.hme_search_method == 1);
+        const int nl       = d.num_of_list_to_search;
+        const int job      = gjob - (int)hdr.job_base[pic];
         const uint32_t bxi = (uint32_t)job % p.w64, byi = p.row0 + (uint32_t)job / p.w64;
         const uint32_t b   = bxi + byi * p.w64;
 
@@ -1502,17 +1510,28 @@ svt_hip_me_b64_kernel(const MeKernelParams *__restrict__ gparams) {
         __syncthreads();
         PROF(16);
     }
-    PROF_FLUSH(p.queue_head + 16);
+    PROF_FLUSH(hdr.queue_head + 16);
 }
 
 size_t svt_hip_me_kernel_lds_bytes(void) { return sizeof(Shared); }
 
 #include "svt_hip_internal.h"
 
-// Host launcher: zero the band queues, size the grid from residency (2 workgroups per CU at this kernel's
-// register/LDS footprint) and enqueue on the context stream.
-int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, uint32_t n_jobs) {
-    if (n_jobs == 0) return SVT_HIP_OK;
+// Host launcher: zero the band queues, copy the header + parameter blocks to HBM (stream ordered: the previous launch
+// has consumed the buffer before this copy lands) and enqueue the persistent workgroups on the context stream.
+int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures) {
+    if (n_pictures == 0 || n_pictures > SVT_HIP_ME_MAX_PICTURES) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "%u pictures in one ME launch (1..%d)", n_pictures, SVT_HIP_ME_MAX_PICTURES);
+    MeBatchHeader hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.n_pictures = n_pictures;
+    for (uint32_t i = 0; i < n_pictures; i++) hdr.job_base[i + 1] = hdr.job_base[i] + n_jobs[i];
+    for (uint32_t i = n_pictures; i < SVT_HIP_ME_MAX_PICTURES; i++) hdr.job_base[i + 1] = hdr.job_base[n_pictures];
+    const uint32_t total = hdr.job_base[n_pictures];
+    if (total == 0) return SVT_HIP_OK;
+    // eight contiguous ranges of the job space, one queue each: neighbouring blocks share reference windows -> same XCD L2.
+    // Ranges are cut at multiples of 4 jobs so that a queue boundary does not split a row needlessly finely.
+    for (int q = 0; q <= SVT_HIP_ME_QUEUES; q++) hdr.queue_begin[q] = (uint32_t)(((uint64_t)total * q) / SVT_HIP_ME_QUEUES);
+    hdr.queue_head = ctx->queue_head;
     SVT_HIP_CHECK(ctx, hipMemsetAsync(ctx->queue_head, 0, SVT_HIP_ME_QUEUES * sizeof(uint32_t), ctx->stream));
     const size_t lds = sizeof(Shared);
     static bool  attr_set = false;
@@ -1522,10 +1541,12 @@ int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, uint32_t
         attr_set = true;
     }
     uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)SVT_HIP_ME_WG_PER_CU; // persistent workgroups: what the launch bounds and the LDS footprint keep resident
-    if (grid > n_jobs) grid = n_jobs;
-    // parameter block -> HBM (stream ordered: the previous launch has consumed the buffer before this copy lands)
-    SVT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->me_params, params, sizeof(MeKernelParams), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, ctx->stream, static_cast<const MeKernelParams *>(ctx->me_params));
+    if (grid > total) grid = total;
+    uint8_t *dev = static_cast<uint8_t *>(ctx->me_params);
+    SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev, &hdr, sizeof(hdr), hipMemcpyHostToDevice, ctx->stream));
+    SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev + SVT_HIP_ME_HEADER_BYTES, params, sizeof(MeKernelParams) * n_pictures, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, ctx->stream, reinterpret_cast<const MeBatchHeader *>(dev),
+                       reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES));
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }

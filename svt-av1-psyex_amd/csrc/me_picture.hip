@@ -88,27 +88,41 @@ size_t layout(const Geometry &g, const SvtHipMePictureDesc *d, const SvtHipMeRes
 
 extern "C" {
 
+int svt_hip_me_pictures_async(SvtHipContext *ctx, uint32_t n_pictures, const SvtHipMeJob *jobs) {
+    if (!ctx || !jobs || n_pictures == 0) return SVT_HIP_ERR_BAD_PARAM;
+    if (n_pictures > SVT_HIP_ME_MAX_PICTURES) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "%u pictures in one call (at most %d)", n_pictures, SVT_HIP_ME_MAX_PICTURES);
+    static thread_local MeKernelParams params[SVT_HIP_ME_MAX_PICTURES];
+    uint32_t n_jobs[SVT_HIP_ME_MAX_PICTURES];
+    for (uint32_t i = 0; i < n_pictures; i++) {
+        const SvtHipMeJob &j = jobs[i];
+        Geometry g;
+        int rc = validate(ctx, j.cfg, j.desc, j.cur, j.refs, j.results, &g);
+        if (rc) return rc;
+        MeKernelParams &p = params[i];
+        memset(&p, 0, sizeof(p));
+        dev_me_config(p.cfg, *j.cfg);
+        dev_me_desc(p.desc, *j.desc);
+        p.cur = j.cur->pyr;
+        for (int li = 0; li < j.desc->num_of_list_to_search; li++)
+            for (int ri = 0; ri < j.desc->num_of_ref_pic_to_search[li]; ri++) p.ref[li][ri] = j.refs[li][ri]->pyr;
+        p.res  = *j.results;
+        p.w64  = g.w64;
+        p.row0 = g.row0;
+        p.n_pu = g.n_pu;
+        n_jobs[i] = g.nrow * g.w64;
+    }
+    hipSetDevice(ctx->device);
+    return svt_hip_me_launch(ctx, params, n_jobs, n_pictures);
+}
+
 int svt_hip_me_picture_async(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, const SvtHipPaPicture *cur,
                              const SvtHipPaPicture *const refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS], const SvtHipMeResults *res_dev) {
-    Geometry g;
-    int rc = validate(ctx, cfg, desc, cur, refs, res_dev, &g);
-    if (rc) return rc;
-    MeKernelParams p;
-    memset(&p, 0, sizeof(p));
-    dev_me_config(p.cfg, *cfg);
-    dev_me_desc(p.desc, *desc);
-    p.cur  = cur->pyr;
-    for (int li = 0; li < desc->num_of_list_to_search; li++)
-        for (int ri = 0; ri < desc->num_of_ref_pic_to_search[li]; ri++) p.ref[li][ri] = refs[li][ri]->pyr;
-    p.res  = *res_dev;
-    p.w64  = g.w64;
-    p.row0 = g.row0;
-    p.n_pu = g.n_pu;
-    // eight contiguous row bands, one queue each (neighbouring blocks share reference windows -> same XCD L2)
-    for (int q = 0; q <= SVT_HIP_ME_QUEUES; q++) p.queue_begin[q] = (uint32_t)(((uint64_t)g.nrow * q) / SVT_HIP_ME_QUEUES) * g.w64;
-    p.queue_head = ctx->queue_head;
-    hipSetDevice(ctx->device);
-    return svt_hip_me_launch(ctx, &p, g.nrow * g.w64);
+    if (!refs) return SVT_HIP_ERR_BAD_PARAM;
+    SvtHipMeJob job;
+    job.cfg = cfg; job.desc = desc; job.cur = cur; job.results = res_dev;
+    for (int li = 0; li < SVT_HIP_MAX_LISTS; li++)
+        for (int ri = 0; ri < SVT_HIP_MAX_REFS; ri++) job.refs[li][ri] = refs[li][ri];
+    return svt_hip_me_pictures_async(ctx, 1, &job);
 }
 
 int svt_hip_me_picture(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, const SvtHipPaPicture *cur,

@@ -119,7 +119,7 @@ int svt_hip_context_create(SvtHipContext **out, int device) {
     ctx->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->queue_head), 512) != hipSuccess || hipMemset(ctx->queue_head, 0, 512) != hipSuccess ||
-        hipMalloc(&ctx->me_params, sizeof(MeKernelParams)) != hipSuccess) {
+        hipMalloc(&ctx->me_params, SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * SVT_HIP_ME_MAX_PICTURES) != hipSuccess) {
         free(ctx);
         return SVT_HIP_ERR_NO_DEVICE;
     }

@@ -11,7 +11,7 @@ struct SvtHipContext {
     int         num_cus;
     hipStream_t stream;
     uint32_t   *queue_head; // SVT_HIP_ME_QUEUES counters in HBM
-    void       *me_params;  // device copy of the ME kernel's MeKernelParams
+    void       *me_params;  // device copy of the ME launch's MeBatchHeader (SVT_HIP_ME_HEADER_BYTES) + MeKernelParams[SVT_HIP_ME_MAX_PICTURES]
     // scratch result buffers of the synchronous (host-pointer) entry points, grown on demand
     void  *scratch;
     size_t scratch_bytes;
@@ -44,7 +44,7 @@ static inline int svt_hip_fail(SvtHipContext *ctx, int code, const char *fmt, ..
 
 // me_kernel.hip
 size_t svt_hip_me_kernel_lds_bytes(void);
-int    svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, uint32_t n_jobs);
+int    svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures);
 // pictures.hip
 int    svt_hip_scratch(SvtHipContext *ctx, size_t bytes, void **out);
 #endif

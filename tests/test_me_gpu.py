@@ -140,3 +140,47 @@ def test_fuzzed_search_controls_match_oracle(hip_ctx, seed):
                   temporal_layer_index=int(rng.integers(0, 3)) if (1, 0) not in refs else 1 + int(rng.integers(0, 3)),
                   cfg_edit=_fuzz_cfg(rng), gm_enabled=seed % 2)
     assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
+
+
+def test_several_pictures_in_one_launch(hip_ctx):
+    """svt_hip_me_pictures_async: three different pictures (sizes, presets, reference counts, a row band) share one launch;
+    each must equal its own single-picture call."""
+    import ctypes as C
+    import torch
+    from svt_av1_psyex_amd import abi
+    cases = [MeCase(352, 288, enc_mode=6), MeCase(640, 360, enc_mode=3, seed=3),
+             MeCase(352, 288, enc_mode=0, cur=2, refs={(0, 0): 1, (0, 1): 0, (1, 0): 3, (1, 1): 4}, n_frames=5)]
+    cases[1].desc.b64_row_start, cases[1].desc.b64_row_count = 2, 3
+    jobs, keep, expect = [], [], []
+    for c in cases:
+        cur = hip_ctx.upload(c.cur)
+        refs = {k: hip_ctx.upload(v) for k, v in c.refs.items()}
+        expect.append(hip_ctx.me_picture(c.cfg, c.desc, cur, refs))
+        n = abi.n_pu(c.desc.enable_me_16x16, c.desc.enable_me_8x8)
+        nb = ((c.desc.aligned_width + 63) // 64) * ((c.desc.aligned_height + 63) // 64)
+        res, bufs = abi.MeResults(), {}
+        for name, dt, cnt in abi.RESULT_FIELDS:
+            bufs[name] = torch.zeros(nb * cnt(n, c.desc.max_refs, c.desc.max_cand) * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+            setattr(res, name, bufs[name].data_ptr())
+        jobs.append((c.cfg, c.desc, cur, refs, res))
+        keep.append((bufs, nb, n))
+    torch.cuda.synchronize()
+    hip_ctx.me_pictures_async(jobs)
+    hip_ctx.sync()
+    for c, (bufs, nb, n), exp in zip(cases, keep, expect):
+        got = {name: bufs[name].cpu().numpy().view(dt).reshape(nb, -1) for name, dt, _ in abi.RESULT_FIELDS}
+        w64 = (c.desc.aligned_width + 63) // 64
+        r0 = c.desc.b64_row_start
+        r1 = r0 + (c.desc.b64_row_count or ((c.desc.aligned_height + 63) // 64 - r0))
+        rows = slice(r0 * w64, r1 * w64)  # the synchronous entry returns only the band's rows as well
+        bad = [k for k in exp if not np.array_equal(np.asarray(exp[k]).reshape(nb, -1)[rows], got[k][rows])]
+        assert not bad, bad
+    # more than 16 pictures in one call is refused
+    assert api_rc_too_many(hip_ctx, jobs[0]) == 2
+
+
+def api_rc_too_many(ctx, job):
+    import ctypes as C
+    from svt_av1_psyex_amd import abi, api
+    arr = (abi.MeJob * 17)()
+    return api.lib().svt_hip_me_pictures_async(ctx._h, 17, arr)
