@@ -250,8 +250,14 @@ def main():
         frac_rows = (wl.row1 - wl.row0) / wl.h64
         me_bytes = (1.3125 * (1 + R) + 0.166 * R) * W * H * frac_rows * len(DISTS)  # B_ME bytes per pixel x the 4 pictures of one launch
         rd_bytes = wl.rd_pixels * (2 * 2 + 4 + 2)  # B_RD = 2*bpp + 4 (+bpp recon), bpp = 2; the step's three launches
-        dom = "me" if kms["me"] >= kms["rd"] else "rd"
-        ach = (me_bytes if dom == "me" else rd_bytes) / (kms[dom] * 1e-3) / 1e9
+        dom = "me" if kms["me"] >= kms["rd"] / len(RD_SIZES) else "rd"  # the single kernel with the longest launch
+        # HBM bytes per launch from the PMC passes committed under profiles/ (same command, N = 1): rocprofv3 cannot run
+        # inside this process, so the figure is the recorded one; null when it does not describe this run
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if world == 1 and dom == "me" and os.path.exists(tf):
+            traffic = json.load(open(tf))["kernels"].get("svt_hip_me_b64_kernel", {}).get("hbm_bytes_per_launch")
+        ach = (me_bytes if dom == "me" else rd_bytes) / (kms[dom] * 1e-3) / 1e9  # rd: the three launches together
         out = {
             "metric": "ME+RD-cost Mpixels/s (2160p10 preset-6)", "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
@@ -260,7 +266,7 @@ def main():
                                    "open-loop ME of all 2040 b64 + full-pel pred + RD chain (64x64,32x32,16x16 DCT_DCT, 10-bit, b quantizer)",
                        "pictures_per_step": len(DISTS), "b64_rows_per_rank": wl.row1 - wl.row0, "parallelism": f"b64-row bands x{world} + all-gather of ME results"},
             "roofline": {"bound": "hbm", "kernel": "svt_hip_me_b64_kernel" if dom == "me" else "rd_tx_kernel (3 sizes)", "achieved": round(ach, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(me_bytes if dom == "me" else rd_bytes), "avg_launch_ms": round(kms[dom], 4)},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
         }
