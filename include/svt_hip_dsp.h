@@ -75,7 +75,8 @@ int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d);
  *                                                                   (C_DEFAULT/picture_operators_c.c:65-83, Codec/pic_operators.c:174-197)
  *   svt_aom_variance{W}x{H}_c                                       (C_DEFAULT/variance.c:256-296)
  *   hadamard_path_c = residual -> svt_aom_hadamard_NxN -> svt_aom_satd over <= 32x32 tiles
- *                                                                   (Codec/enc_mode_config.c:2151-2217)                     */
+ *                                                                   (Codec/enc_mode_config.c:2151-2217)
+ *   svt_psy_distortion / svt_psy_distortion_hbd / get_svt_psy_full_dist  (Codec/psy_rd.c:135-293)                           */
 typedef struct SvtHipBlockJob {
     uint32_t src_offset, ref_offset; /* sample offsets of the block's top-left sample in the two planes */
     uint8_t  width, height;          /* 1..128 */
@@ -95,6 +96,10 @@ typedef struct SvtHipBlockStatsDesc {
     uint32_t *variance; /* sse32 - sum^2 / (w*h), the svt_aom_variance* return value (32-bit wrap like the reference) */
     uint32_t *var_sse;  /* the `sse` out-parameter of svt_aom_variance* (32-bit) */
     uint32_t *satd;     /* hadamard_path_c of a square block (4..128); 0 for other shapes; 8-bit planes only */
+    /* PSYEX psy-RD term (Codec/psy_rd.c:135-293): src = input, ref = reconstruction; width and height multiples of 4 */
+    double    psy_rd;     /* strength; only used for psy_dist */
+    uint64_t *psy_energy; /* svt_psy_distortion / svt_psy_distortion_hbd */
+    uint64_t *psy_dist;   /* get_svt_psy_full_dist: (uint64_t)(psy_energy * psy_rd), one fp64 multiply */
 } SvtHipBlockStatsDesc;
 
 /* Enqueues one batch on the context stream (asynchronous); one wave per job. */

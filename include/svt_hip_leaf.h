@@ -57,6 +57,12 @@ int  svt_aom_satd_hip(const int32_t *coeff, int length);
  * square block of `block_size_wide` (4..128) */
 uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide);
 
+/* PSYEX psy-RD term (Codec/psy_rd.h:23-33): integer energies, and the fp64-scaled form */
+uint64_t svt_psy_distortion_hip(const uint8_t *input, uint32_t input_stride, const uint8_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height);
+uint64_t svt_psy_distortion_hbd_hip(const uint16_t *input, uint32_t input_stride, const uint16_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height);
+uint64_t get_svt_psy_full_dist_hip(const void *s, uint32_t so, uint32_t sp, const void *r, uint32_t ro, uint32_t rp, uint32_t w, uint32_t h, uint8_t is_hbd,
+                                   double psy_rd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,6 +102,9 @@ def gen_presets():
     print("wrote me_presets", len(keys))
 
 
+PSY_RD = 1.35  # strength used for the psy_dist column of the block-statistics fixture
+
+
 def gen_block_stats():
     """Block statistics (SAD / SSE / variance / hadamard_path SATD) of the reference's `_c` kernels on two small planes."""
     from svt_av1_psyex_amd import abi, stats
@@ -122,12 +125,17 @@ def gen_block_stats():
         src[64:128, :64] = 0; refp[64:128, :64] = (1 << bd) - 1
         jobs = stats.random_jobs(rng, W, H, 160)
         jobs[0] = (0, 0, 64, 64, (0, 0)); jobs[1] = (64 * W, 64 * W, 64, 64, (0, 0)); jobs[2] = (0, 64 * W, 32, 32, (0, 0))
-        exp = {name: np.zeros(len(jobs), dtype=d) for name, d in abi.STATS_OUT_FIELDS}
+        exp = {name: np.zeros(len(jobs), dtype=d) for name, d in abi.STATS_OUT_FIELDS + abi.PSY_OUT_FIELDS}
+        ref.svt_psy_distortion.restype = ref.svt_psy_distortion_hbd.restype = ref.get_svt_psy_full_dist.restype = C.c_uint64
         for j, jb in enumerate(jobs):
             w, h = int(jb["width"]), int(jb["height"])
             s = src.reshape(-1)[int(jb["src_offset"]):]
             r = refp.reshape(-1)[int(jb["ref_offset"]):]
             vs = C.c_uint32()
+            fpsy = ref.svt_psy_distortion if bd == 8 else ref.svt_psy_distortion_hbd
+            exp["psy_energy"][j] = fpsy(ptr(s), C.c_uint32(W), ptr(r), C.c_uint32(W), C.c_uint32(w), C.c_uint32(h))
+            exp["psy_dist"][j] = ref.get_svt_psy_full_dist(ptr(s), C.c_uint32(0), C.c_uint32(W), ptr(r), C.c_uint32(0), C.c_uint32(W), C.c_uint32(w), C.c_uint32(h),
+                                                           C.c_uint8(bd != 8), C.c_double(PSY_RD))
             if bd == 8:
                 exp["sad"][j] = ref.svt_nxm_sad_kernel_helper_c(ptr(s), C.c_uint32(W), ptr(r), C.c_uint32(W), C.c_uint32(h), C.c_uint32(w))
                 exp["sse"][j] = ref.svt_spatial_full_distortion_kernel_c(ptr(s), C.c_uint32(0), C.c_uint32(W), ptr(r), C.c_int32(0), C.c_uint32(W), C.c_uint32(w), C.c_uint32(h))

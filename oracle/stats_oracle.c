@@ -44,6 +44,95 @@ uint32_t orc_hadamard_path(const uint8_t *input, uint32_t input_stride, const ui
     return cost;
 }
 
+/* PSYEX psy-RD energy term, Codec/psy_rd.c:64-168 (8-bit) and :171-274 (10-bit).
+ * 8-bit: the reference evaluates the Hadamard sums two columns at a time in packed 2 x 16-bit integers; with pixel
+ * inputs (against its all-zero buffer) no packed half can overflow -- sum |c| over 8 coefficients <=
+ * sqrt(8 * 64 * 64 * 255^2) < 2^16 -- so the packed arithmetic equals the plain unnormalised 2-D Hadamard:
+ * sa8d = (sum |H8 X H8'| + 2) >> 2, satd4 = sum |H4 X H4'| >> 1.
+ * 10-bit: the reference packs 2 x 32 bits into 64, but its 4-point butterflies (the HADAMARD4 macro used at
+ * psy_rd.c:189,192-193,220) keep their temporaries in 32 bits: only the low half survives every butterfly, zero-extended,
+ * and the per-half absolute value (psy_rd.c:54-59) then sees carries / borrows of the 64-bit sums in the high half.
+ * That arithmetic is part of the encoder's behaviour, so it is restated bit for bit below (pack32 / bfly_low / abs_halves).
+ * The block's "energy" is the Hadamard sum minus (sum of pixels) >> 2; the distortion sums |energy(input) -
+ * energy(recon)| over the 8x8 tiles (4x4 tiles when a side is below 8) and scales by >> 1 (8-bit) or << 2 (10-bit). */
+static void had1d(int32_t *v, int n, int stride) {
+    for (int len = 1; len < n; len <<= 1)
+        for (int i = 0; i < n; i += 2 * len)
+            for (int j = i; j < i + len; j++) {
+                const int32_t a = v[j * stride], b = v[(j + len) * stride];
+                v[j * stride] = a + b; v[(j + len) * stride] = a - b;
+            }
+}
+static uint64_t pack32(int32_t x0, int32_t x1) { return (uint64_t)(int64_t)(x0 + x1) + ((uint64_t)(int64_t)(x0 - x1) << 32); }
+static void bfly_low(uint64_t d[4], uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3) { /* 4-point butterfly carried out in 32 bits */
+    const uint32_t t0 = (uint32_t)(s0 + s1), t1 = (uint32_t)(s0 - s1), t2 = (uint32_t)(s2 + s3), t3 = (uint32_t)(s2 - s3);
+    d[0] = (uint32_t)(t0 + t2); d[1] = (uint32_t)(t1 + t3); d[2] = (uint32_t)(t0 - t2); d[3] = (uint32_t)(t1 - t3);
+}
+static uint64_t abs_halves(uint64_t a) { /* |.| of the two 32-bit halves, in the borrow-compensating form of the reference */
+    const uint64_t m = (a >> 31) & 0x100000001ull, s = (m << 32) - m;
+    return (a + s) ^ s;
+}
+static uint64_t fold_halves(uint64_t b) { return (uint32_t)b + (b >> 32); }
+static int64_t psy_had16(const uint16_t *p, uint32_t stride, int n) {
+    uint64_t t[8][4], sum = 0;
+    if (n == 8) {
+        for (int i = 0; i < 8; i++) {
+            const uint16_t *r = p + (size_t)i * stride;
+            bfly_low(t[i], pack32(r[0], r[1]), pack32(r[2], r[3]), pack32(r[4], r[5]), pack32(r[6], r[7]));
+        }
+        for (int i = 0; i < 4; i++) {
+            uint64_t a[8], b = 0;
+            bfly_low(a, t[0][i], t[1][i], t[2][i], t[3][i]);
+            bfly_low(a + 4, t[4][i], t[5][i], t[6][i], t[7][i]);
+            for (int k = 0; k < 4; k++) b += abs_halves(a[k] + a[k + 4]) + abs_halves(a[k] - a[k + 4]);
+            sum += fold_halves(b);
+        }
+        return (int64_t)((sum + 2) >> 2);
+    }
+    for (int i = 0; i < 4; i++) {
+        const uint16_t *r = p + (size_t)i * stride;
+        const uint64_t b0 = pack32(r[0], r[1]), b1 = pack32(r[2], r[3]);
+        t[i][0] = b0 + b1; t[i][1] = b0 - b1;
+    }
+    for (int i = 0; i < 2; i++) {
+        uint64_t a[4];
+        bfly_low(a, t[0][i], t[1][i], t[2][i], t[3][i]);
+        sum += fold_halves(abs_halves(a[0]) + abs_halves(a[1]) + abs_halves(a[2]) + abs_halves(a[3]));
+    }
+    return (int64_t)(sum >> 1);
+}
+static int32_t psy_tile_energy(const void *pix, int is16, uint32_t stride, int n) {
+    int32_t m[64];
+    int64_t sum = 0, acc = 0, had;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            const int32_t v = is16 ? ((const uint16_t *)pix)[(size_t)y * stride + x] : ((const uint8_t *)pix)[(size_t)y * stride + x];
+            m[y * n + x] = v;
+            sum += v;
+        }
+    if (is16) had = psy_had16((const uint16_t *)pix, stride, n);
+    else {
+        for (int y = 0; y < n; y++) had1d(m + y * n, n, 1);
+        for (int x = 0; x < n; x++) had1d(m + x, n, n);
+        for (int i = 0; i < n * n; i++) acc += m[i] < 0 ? -m[i] : m[i];
+        had = n == 8 ? (acc + 2) >> 2 : acc >> 1;
+    }
+    return (int32_t)(had - (sum >> 2));
+}
+uint64_t orc_psy_distortion(const void *input, uint32_t input_stride, const void *recon, uint32_t recon_stride, uint32_t width, uint32_t height,
+                            int is16) {
+    const int n   = (width >= 8 && height >= 8) ? 8 : 4;
+    const size_t bpp = is16 ? 2 : 1;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < height; i += n)
+        for (uint32_t j = 0; j < width; j += n) {
+            const int32_t a = psy_tile_energy((const uint8_t *)input + ((size_t)i * input_stride + j) * bpp, is16, input_stride, n);
+            const int32_t b = psy_tile_energy((const uint8_t *)recon + ((size_t)i * recon_stride + j) * bpp, is16, recon_stride, n);
+            total += (uint64_t)(a > b ? a - b : b - a);
+        }
+    return is16 ? total << 2 : total >> 1;
+}
+
 int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
     if (!d || (d->bit_depth != 8 && d->bit_depth != 10) || !d->src || !d->ref || !d->jobs) return 2;
     if (d->satd && d->bit_depth != 8) return 2;
@@ -66,6 +155,14 @@ int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
             sad = orc_sad_16b(s, d->src_stride, r, d->ref_stride, (uint32_t)h, (uint32_t)w);
             sse = orc_spatial_sse16(s, 0, d->src_stride, r, 0, d->ref_stride, (uint32_t)w, (uint32_t)h);
             var = orc_variance16(s, (int)d->src_stride, r, (int)d->ref_stride, w, h, &vsse);
+        }
+        if (d->psy_energy || d->psy_dist) {
+            if ((w & 3) || (h & 3)) return 2;
+            const size_t bpp = d->bit_depth == 8 ? 1 : 2;
+            const uint64_t e = orc_psy_distortion((const uint8_t *)d->src + (size_t)jb.src_offset * bpp, d->src_stride,
+                                                  (const uint8_t *)d->ref + (size_t)jb.ref_offset * bpp, d->ref_stride, (uint32_t)w, (uint32_t)h, d->bit_depth != 8);
+            if (d->psy_energy) d->psy_energy[j] = e;
+            if (d->psy_dist) d->psy_dist[j] = (uint64_t)((double)e * d->psy_rd); /* get_svt_psy_full_dist, psy_rd.c:277-293 */
         }
         if (d->sad) d->sad[j] = sad;
         if (d->sse) d->sse[j] = sse;

@@ -124,6 +124,108 @@ __device__ void hadamard_tile(HadLds &L, int n, int lane) {
     }
 }
 
+// ---- PSYEX psy-RD energy (Codec/psy_rd.c:64-274) -----------------------------------------------------------------
+// 8-bit: the reference's packed 2 x 16-bit Hadamard never overflows a half on pixel data, so it equals the plain
+// unnormalised 2-D Hadamard.  10-bit: its 4-point butterflies keep 32-bit temporaries, so only the low half of the
+// packed 2 x 32-bit values survives each butterfly; restated bit for bit (see oracle/stats_oracle.c for the derivation).
+__device__ __forceinline__ void had8_inplace(int32_t *v) { // unnormalised 8-point Hadamard of v[0..7]
+#pragma unroll
+    for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < 8; i += 2 * len)
+#pragma unroll
+            for (int j = i; j < i + len; j++) { const int32_t a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
+}
+__device__ __forceinline__ u64 pack32(int32_t x0, int32_t x1) { return (u64)(i64)(x0 + x1) + ((u64)(i64)(x0 - x1) << 32); }
+__device__ __forceinline__ void bfly_low(u64 d[4], u64 s0, u64 s1, u64 s2, u64 s3) {
+    const uint32_t t0 = (uint32_t)(s0 + s1), t1 = (uint32_t)(s0 - s1), t2 = (uint32_t)(s2 + s3), t3 = (uint32_t)(s2 - s3);
+    d[0] = (uint32_t)(t0 + t2); d[1] = (uint32_t)(t1 + t3); d[2] = (uint32_t)(t0 - t2); d[3] = (uint32_t)(t1 - t3);
+}
+__device__ __forceinline__ u64 abs_halves(u64 a) { const u64 m = (a >> 31) & 0x100000001ull, s = (m << 32) - m; return (a + s) ^ s; }
+__device__ __forceinline__ u64 fold_halves(u64 b) { return (uint32_t)b + (b >> 32); }
+
+// energy of one n x n tile (n = 8 or 4) of plane p: Hadamard sum - (sum of pixels >> 2)
+template <typename Pix> __device__ int32_t psy_tile_energy(const Pix *p, uint32_t stride, int n) {
+    i64 sum = 0, had;
+    if (sizeof(Pix) == 1) {
+        int32_t m[8][8];
+        if (n == 8) {
+#pragma unroll
+            for (int y = 0; y < 8; y++) {
+#pragma unroll
+                for (int x = 0; x < 8; x++) { m[y][x] = (int32_t)p[(size_t)y * stride + x]; sum += m[y][x]; }
+                had8_inplace(m[y]);
+            }
+            i64 acc = 0;
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                int32_t c[8];
+#pragma unroll
+                for (int y = 0; y < 8; y++) c[y] = m[y][x];
+                had8_inplace(c);
+#pragma unroll
+                for (int y = 0; y < 8; y++) acc += c[y] < 0 ? -c[y] : c[y];
+            }
+            had = (acc + 2) >> 2;
+        } else {
+            int32_t q[4][4];
+            i64     acc = 0;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) { q[y][x] = (int32_t)p[(size_t)y * stride + x]; sum += q[y][x]; }
+                const int32_t a = q[y][0] + q[y][1], b = q[y][0] - q[y][1], c = q[y][2] + q[y][3], d = q[y][2] - q[y][3];
+                q[y][0] = a + c; q[y][1] = b + d; q[y][2] = a - c; q[y][3] = b - d;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int32_t a = q[0][x] + q[1][x], b = q[0][x] - q[1][x], c = q[2][x] + q[3][x], d = q[2][x] - q[3][x];
+                const int32_t o0 = a + c, o1 = b + d, o2 = a - c, o3 = b - d;
+                acc += (o0 < 0 ? -o0 : o0) + (o1 < 0 ? -o1 : o1) + (o2 < 0 ? -o2 : o2) + (o3 < 0 ? -o3 : o3);
+            }
+            had = acc >> 1;
+        }
+    } else {
+        u64 t[8][4], hs = 0;
+        if (n == 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int32_t r[8];
+#pragma unroll
+                for (int x = 0; x < 8; x++) { r[x] = (int32_t)p[(size_t)i * stride + x]; sum += r[x]; }
+                bfly_low(t[i], pack32(r[0], r[1]), pack32(r[2], r[3]), pack32(r[4], r[5]), pack32(r[6], r[7]));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                u64 a[8], b = 0;
+                bfly_low(a, t[0][i], t[1][i], t[2][i], t[3][i]);
+                bfly_low(a + 4, t[4][i], t[5][i], t[6][i], t[7][i]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) b += abs_halves(a[k] + a[k + 4]) + abs_halves(a[k] - a[k + 4]);
+                hs += fold_halves(b);
+            }
+            had = (i64)((hs + 2) >> 2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int32_t r[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) { r[x] = (int32_t)p[(size_t)i * stride + x]; sum += r[x]; }
+                const u64 b0 = pack32(r[0], r[1]), b1 = pack32(r[2], r[3]);
+                t[i][0] = b0 + b1; t[i][1] = b0 - b1;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                u64 a[4];
+                bfly_low(a, t[0][i], t[1][i], t[2][i], t[3][i]);
+                hs += fold_halves(abs_halves(a[0]) + abs_halves(a[1]) + abs_halves(a[2]) + abs_halves(a[3]));
+            }
+            had = (i64)(hs >> 1);
+        }
+    }
+    return (int32_t)(had - (sum >> 2));
+}
+
 struct StatsParams {
     SvtHipBlockStatsDesc d;
 };
@@ -177,6 +279,22 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         }
         satd = wave_sum(satd);
         if (lane == 0) p.d.satd[job] = satd;
+    }
+    if (p.d.psy_energy || p.d.psy_dist) { // svt_psy_distortion{,_hbd}: one lane per 8x8 (or 4x4) tile
+        const int n = (w >= 8 && h >= 8) ? 8 : 4, ntx = (w + n - 1) / n, nt = ntx * ((h + n - 1) / n); // the reference's loops: i < height; i += n
+        u64 total = 0;
+        for (int t = lane; t < nt; t += 64) {
+            const int ty = t / ntx, tx = t - ty * ntx;
+            const int32_t a = psy_tile_energy<Pix>(src + (size_t)(ty * n) * p.d.src_stride + tx * n, p.d.src_stride, n);
+            const int32_t b = psy_tile_energy<Pix>(ref + (size_t)(ty * n) * p.d.ref_stride + tx * n, p.d.ref_stride, n);
+            total += (u64)(a > b ? a - b : b - a);
+        }
+        total = wave_sum(total);
+        const u64 e = sizeof(Pix) == 1 ? total >> 1 : total << 2;
+        if (lane == 0) {
+            if (p.d.psy_energy) p.d.psy_energy[job] = e;
+            if (p.d.psy_dist) p.d.psy_dist[job] = (u64)((double)e * p.d.psy_rd); // get_svt_psy_full_dist, psy_rd.c:277-293
+        }
     }
 }
 
@@ -295,10 +413,11 @@ void upload_rows(SvtHipContext *ctx, void *dst, const void *src, size_t stride_b
     leaf_check(ctx, hipMemcpyAsync(dst, src, (rows - 1) * stride_bytes + row_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
 }
 
-struct StatsOut { uint32_t sad, variance, var_sse, satd; u64 sse; };
+struct StatsOut { uint32_t sad, variance, var_sse, satd; u64 sse, psy_energy, psy_dist; };
 
 // one (src, ref) block through block_stats_kernel
-StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t ref_stride, int w, int h, int bit_depth, bool want_satd) {
+StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t ref_stride, int w, int h, int bit_depth, bool want_satd,
+                    bool want_psy = false, double psy_rd = 0.0) {
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
@@ -318,6 +437,7 @@ StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t 
     d.src = d_src; d.ref = d_ref; d.jobs = reinterpret_cast<const SvtHipBlockJob *>(d_job);
     StatsOut *o = reinterpret_cast<StatsOut *>(d_out);
     d.sad = &o->sad; d.variance = &o->variance; d.var_sse = &o->var_sse; d.sse = reinterpret_cast<uint64_t *>(&o->sse); d.satd = want_satd ? &o->satd : nullptr;
+    if (want_psy) { d.psy_rd = psy_rd; d.psy_energy = reinterpret_cast<uint64_t *>(&o->psy_energy); d.psy_dist = reinterpret_cast<uint64_t *>(&o->psy_dist); }
     if (svt_hip_block_stats_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
     StatsOut out;
     memset(&out, 0, sizeof(out));
@@ -403,6 +523,19 @@ uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_of
                                                uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
     return leaf_stats(reinterpret_cast<uint16_t *>(input) + input_offset, input_stride, reinterpret_cast<uint16_t *>(recon) + recon_offset, recon_stride,
                       (int)area_width, (int)area_height, 10, false).sse;
+}
+
+uint64_t svt_psy_distortion_hip(const uint8_t *input, uint32_t input_stride, const uint8_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height) {
+    return leaf_stats(input, input_stride, recon, recon_stride, (int)width, (int)height, 8, false, true, 0.0).psy_energy;
+}
+uint64_t svt_psy_distortion_hbd_hip(const uint16_t *input, uint32_t input_stride, const uint16_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height) {
+    return leaf_stats(input, input_stride, recon, recon_stride, (int)width, (int)height, 10, false, true, 0.0).psy_energy;
+}
+uint64_t get_svt_psy_full_dist_hip(const void *s, uint32_t so, uint32_t sp, const void *r, uint32_t ro, uint32_t rp, uint32_t w, uint32_t h, uint8_t is_hbd,
+                                   double psy_rd) {
+    if (is_hbd == 1)
+        return leaf_stats(static_cast<const uint16_t *>(s) + so, sp, static_cast<const uint16_t *>(r) + ro, rp, (int)w, (int)h, 10, false, true, psy_rd).psy_dist;
+    return leaf_stats(static_cast<const uint8_t *>(s) + so, sp, static_cast<const uint8_t *>(r) + ro, rp, (int)w, (int)h, 8, false, true, psy_rd).psy_dist;
 }
 
 uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide) {

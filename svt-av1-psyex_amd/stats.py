@@ -21,11 +21,17 @@ def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False):
     return jobs
 
 
-def run_oracle(oracle, src, ref, jobs, bit_depth, satd=True):
-    """src / ref: 2-D numpy planes (uint8 or uint16); returns a dict of per-job arrays from oracle/stats_oracle.c"""
+def run_oracle(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
+    """src / ref: 2-D numpy planes (uint8 or uint16); returns a dict of per-job arrays from oracle/stats_oracle.c.
+    psy_rd: also return the psy-RD terms (jobs must then have widths / heights that are multiples of 4)."""
     n = len(jobs)
     out = {name: np.zeros(n, dtype=dt) for name, dt in abi.STATS_OUT_FIELDS}
     d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
+    if psy_rd is not None:
+        d.psy_rd = psy_rd
+        for name, dt in abi.PSY_OUT_FIELDS:
+            out[name] = np.zeros(n, dtype=dt)
+            setattr(d, name, out[name].ctypes.data)
     src, ref, jobs = np.ascontiguousarray(src), np.ascontiguousarray(ref), np.ascontiguousarray(jobs)
     d.src, d.ref, d.jobs = src.ctypes.data, ref.ctypes.data, jobs.ctypes.data
     for name, _ in abi.STATS_OUT_FIELDS:
@@ -40,15 +46,20 @@ def run_oracle(oracle, src, ref, jobs, bit_depth, satd=True):
     return out
 
 
-def run_hip(ctx, src, ref, jobs, bit_depth, satd=True):
+def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
     import torch
     from . import api
     L = api.lib()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
     n = len(jobs)
     t_src, t_ref, t_jobs = dev(src), dev(ref), dev(jobs)
-    outs = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in abi.STATS_OUT_FIELDS}
+    fields = list(abi.STATS_OUT_FIELDS) + (list(abi.PSY_OUT_FIELDS) if psy_rd is not None else [])
+    outs = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in fields}
     d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
+    if psy_rd is not None:
+        d.psy_rd = psy_rd
+        for name, _ in abi.PSY_OUT_FIELDS:
+            setattr(d, name, outs[name].data_ptr())
     d.src, d.ref, d.jobs = t_src.data_ptr(), t_ref.data_ptr(), t_jobs.data_ptr()
     for name, _ in abi.STATS_OUT_FIELDS:
         if name == "satd" and not satd:
@@ -59,7 +70,7 @@ def run_hip(ctx, src, ref, jobs, bit_depth, satd=True):
     if rc:
         raise api.SvtHipError(f"svt_hip_block_stats_batch: {rc} {ctx.last_error()}")
     ctx.sync()
-    res = {name: outs[name].cpu().numpy().view(dt) for name, dt in abi.STATS_OUT_FIELDS}
+    res = {name: outs[name].cpu().numpy().view(dt) for name, dt in fields}
     if not satd:
         res.pop("satd")
     return res

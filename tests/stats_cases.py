@@ -5,19 +5,20 @@ import numpy as np
 
 from svt_av1_psyex_amd import abi
 
+PSY_RD = 1.35  # the strength the fixture's psy_dist column was generated with (oracle/gen_golden.py)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "block_stats.npz")
 
 
 def load_fixture(bd):
     z = np.load(GOLDEN)
     jobs = np.ascontiguousarray(z[f"jobs{bd}"]).view(abi.BLOCK_JOB_DTYPE).reshape(-1)
-    exp = {name: z[f"{name}{bd}"] for name, _ in abi.STATS_OUT_FIELDS}
+    exp = {name: z[f"{name}{bd}"] for name, _ in abi.STATS_OUT_FIELDS + abi.PSY_OUT_FIELDS}
     return z[f"src{bd}"], z[f"ref{bd}"], jobs, exp
 
 
 def mismatches(exp, got, bd):
     bad = []
-    for name, _ in abi.STATS_OUT_FIELDS:
+    for name, _ in abi.STATS_OUT_FIELDS + abi.PSY_OUT_FIELDS:
         if name == "satd" and bd != 8:
             continue
         if name not in got:

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from stats_cases import load_fixture, mismatches
+from stats_cases import PSY_RD, load_fixture, mismatches
 from svt_av1_psyex_amd import abi, api, stats
 
 pytestmark = pytest.mark.gpu
@@ -21,7 +21,7 @@ def p(a):
 @pytest.mark.parametrize("bd", [8, 10])
 def test_batch_matches_reference_fixture(hip_ctx, bd):
     src, ref, jobs, exp = load_fixture(bd)
-    got = stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=(bd == 8))
+    got = stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=(bd == 8), psy_rd=PSY_RD)
     assert not mismatches(exp, got, bd)
 
 
@@ -37,7 +37,13 @@ def test_batch_matches_oracle_on_random_jobs(hip_ctx, oracle, bd):
     jobs = np.concatenate([jobs, odd])
     a = stats.run_oracle(oracle, src, ref, jobs, bd, satd=(bd == 8))
     b = stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=(bd == 8))
-    assert not mismatches(a, b, bd)
+    assert not [m for m in mismatches(a, b, bd) if "psy" not in m]
+    # psy-RD terms: AV1 shapes only (multiples of 4), three strengths incl. 0
+    for psy_rd in (0.0, 0.5, 4.0):
+        jp = jobs[:1500]
+        a = stats.run_oracle(oracle, src, ref, jp, bd, satd=False, psy_rd=psy_rd)
+        b = stats.run_hip(hip_ctx, src, ref, jp, bd, satd=False, psy_rd=psy_rd)
+        assert not [m for m in mismatches(a, b, bd) if "satd" not in m], psy_rd
 
 
 def test_batch_rejects_bad_descriptors(hip_ctx):
@@ -123,3 +129,24 @@ def test_leaf_hadamard_path(leaf, oracle):
         a = rng.integers(0, 256, (n, n + 5)).astype(np.uint8); b = rng.integers(0, 256, (n, n + 9)).astype(np.uint8)
         assert leaf.svt_hip_hadamard_path(p(a), C.c_uint32(n + 5), p(b), C.c_uint32(n + 9), C.c_uint32(n)) == \
             oracle.orc_hadamard_path(p(a), C.c_uint32(n + 5), p(b), C.c_uint32(n + 9), C.c_uint32(n))
+
+
+def test_leaf_psy_distortion(leaf, oracle):
+    rng = np.random.default_rng(21)
+    for name in ("svt_psy_distortion_hip", "svt_psy_distortion_hbd_hip", "get_svt_psy_full_dist_hip"):
+        getattr(leaf, name).restype = C.c_uint64
+    oracle.orc_psy_distortion.restype = C.c_uint64
+    for (w, h) in [(4, 4), (16, 4), (8, 8), (32, 16), (64, 64), (128, 128)]:
+        a = rng.integers(0, 256, (h, w + 3)).astype(np.uint8); b = rng.integers(0, 256, (h, w + 5)).astype(np.uint8)
+        e = oracle.orc_psy_distortion(p(a), C.c_uint32(w + 3), p(b), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(h), C.c_int(0))
+        assert leaf.svt_psy_distortion_hip(p(a), C.c_uint32(w + 3), p(b), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(h)) == e
+        a16 = rng.integers(0, 1024, (h, w + 3)).astype(np.uint16); b16 = rng.integers(0, 1024, (h, w + 5)).astype(np.uint16)
+        e16 = oracle.orc_psy_distortion(p(a16), C.c_uint32(w + 3), p(b16), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(h), C.c_int(1))
+        assert leaf.svt_psy_distortion_hbd_hip(p(a16), C.c_uint32(w + 3), p(b16), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(h)) == e16
+        got = leaf.get_svt_psy_full_dist_hip(p(a16), C.c_uint32(1), C.c_uint32(w + 3), p(b16), C.c_uint32(2), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(h - 4 if h > 8 else h),
+                                             C.c_uint8(1), C.c_double(0.75))
+        hh = h - 4 if h > 8 else h
+        if hh % 8 == 0 or hh < 8 or w < 8:  # keep to whole tiles
+            a2 = a16.reshape(-1)[1:]; b2 = b16.reshape(-1)[2:]
+            want = int(float(oracle.orc_psy_distortion(p(a2), C.c_uint32(w + 3), p(b2), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(hh), C.c_int(1))) * 0.75)
+            assert got == want, (w, h)
