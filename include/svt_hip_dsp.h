@@ -40,7 +40,9 @@ typedef struct SvtHipTxJob {
     uint32_t pred_offset; /* sample offset in the prediction plane (and in the recon plane)       */
     uint8_t  tx_type;
     uint8_t  quant_row;   /* index into SvtHipRdBatchDesc.quant_rows */
-    uint8_t  reserved[2];
+    uint8_t  pf_shape;    /* EB_TRANS_COEFF_SHAPE (Codec/definitions.h): 0 DEFAULT, 1 N2, 2 N4, 3 ONLY_DC -- the partial-frequency
+                           * forward transforms av1_estimate_transform_{N2,N4,ONLY_DC} (Codec/transforms.c:2633-2948) */
+    uint8_t  reserved;
 } SvtHipTxJob;
 
 typedef struct SvtHipRdBatchDesc {
@@ -62,6 +64,10 @@ typedef struct SvtHipRdBatchDesc {
     uint64_t *three_quad_energy;      /* [n_jobs] energy of the frequencies a 64-point size discards (0 otherwise) */
     uint64_t *sse;                    /* [n_jobs] sum (src - recon)^2 */
     int32_t  *coeff, *qcoeff, *dqcoeff; /* optional: [n_jobs][min(W,32)*min(H,32)] packed like the reference */
+    /* optional quantization matrices of this tx_size (device pointers, min(W,32)*min(H,32) bytes each, AOM_QM_BITS = 5 fixed
+     * point: pcs->ppcs->gqmatrix / giqmatrix[level][plane][adjusted_tx_size], full_loop.c:1606-1613); applied to the jobs with
+     * a 2-D tx_type (tx_type < IDTX), like the reference; NULL = flat */
+    const uint8_t *qmatrix, *iqmatrix;
 } SvtHipRdBatchDesc;
 
 /* Enqueues one batch on the context stream (asynchronous).  Every pointer in `d` is a DEVICE pointer.

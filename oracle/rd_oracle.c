@@ -45,12 +45,23 @@ int orc_rd_batch(const SvtHipRdBatchDesc *d) {
         else
             orc_residual8((const uint8_t *)d->src + jb->src_offset, d->src_stride, (const uint8_t *)d->pred + jb->pred_offset, d->pred_stride, res, W, W, H);
         orc_fwd_txfm2d(res, co, W, tt, ts);
+        /* partial-frequency shapes (av1_estimate_transform_N2 / _N4 / _ONLY_DC, transforms.c:2633-2948): the pruned 1-D
+         * kernels produce the full transform's low-frequency outputs, everything else is zeroed (:5266-5270, :6830-6834,
+         * :2936-2946) and no energy is attributed to the discarded quadrants (svt_handle_transform*_N2_N4_c, :2514-2543) */
+        if (jb->pf_shape)
+            for (int r = 0; r < H; r++)
+                for (int c = 0; c < W; c++) {
+                    const int keep = jb->pf_shape == 3 ? (r == 0 && c == 0) : (c < (W >> jb->pf_shape) && r < (H >> jb->pf_shape));
+                    if (!keep) co[r * W + c] = 0;
+                }
         d->three_quad_energy[j] = orc_handle_transform(co, ts);
+        if (jb->pf_shape) d->three_quad_energy[j] = 0;
         d->satd[j]              = (uint32_t)orc_satd(co, NP);
+        const uint8_t *qm = tt < 9 ? d->qmatrix : NULL, *iqm = tt < 9 ? d->iqmatrix : NULL; /* IS_2D_TRANSFORM, full_loop.c:1606-1608 */
         if (d->quant_kind == 0)
-            orc_quantize_b(co, NP, qr->zbin, qr->round, qr->quant, qr->quant_shift, q, dq, qr->dequant, &d->eob[j], scan[kind], NULL, NULL, k_log_scale[ts], hbd);
+            orc_quantize_b(co, NP, qr->zbin, qr->round, qr->quant, qr->quant_shift, q, dq, qr->dequant, &d->eob[j], scan[kind], qm, iqm, k_log_scale[ts], hbd);
         else
-            orc_quantize_fp(co, NP, qr->round_fp, qr->quant_fp, q, dq, qr->dequant, &d->eob[j], scan[kind], NULL, NULL, k_log_scale[ts], hbd);
+            orc_quantize_fp(co, NP, qr->round_fp, qr->quant_fp, q, dq, qr->dequant, &d->eob[j], scan[kind], qm, iqm, k_log_scale[ts], hbd);
         orc_full_distortion32(co, WP, dq, WP, &d->dist_coeff[2 * (size_t)j], WP, HP);
         for (int r = 0; r < H; r++)
             for (int c = 0; c < W; c++)

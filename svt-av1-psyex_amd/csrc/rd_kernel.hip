@@ -408,15 +408,20 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
     }
     __syncthreads();
     // 64-point sizes keep the top-left 32x32 (svt_handle_transform*_c, transforms.c:2374-2505)
+    // partial-frequency shapes (av1_estimate_transform_N2 / _N4 / _ONLY_DC, transforms.c:2633-2948): the pruned 1-D kernels
+    // of the reference produce the full transform's low-frequency outputs; everything else is zero and no energy is
+    // attributed to the discarded frequencies (svt_handle_transform*_N2_N4_c, :2514-2543)
+    const int pf = jb.pf_shape & 3;
+    const int keep_w = pf == 3 ? 1 : (W >> pf), keep_h = pf == 3 ? 1 : (H >> pf);
     u64 tq = 0;
-    if constexpr (W > 32 || H > 32) {
+    if (pf == 0) if constexpr (W > 32 || H > 32) {
         for (int i = l; i < W * H; i += LW) {
             const int r = i / W, c = i - r * W;
             if (r >= HP || c >= WP) { const int32_t v = A[r * PA + c]; tq += (u64)((i64)v * v); }
         }
         tq = seg_sum_u64<LW>(tq);
-        __syncthreads(); // the compaction below overwrites discarded coefficients
     }
+    if constexpr (W > 32 || H > 32) __syncthreads(); // the compaction below overwrites discarded coefficients
     // SATD, quantize, coefficient-domain distortion over the kept NP coefficients (packed index rc = r*WP + c).  The
     // dequantized value replaces the coefficient at the packed position r*PB + c <= r*PA + c: a later iteration never
     // reads what an earlier one overwrote (its reads start beyond the earlier iteration's writes), and within one
@@ -424,6 +429,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
     const SvtHipQuantRow q = p.d.quant_rows[jb.quant_row];
     const int     log_scale = c_log_scale[TS];
     const int16_t *iscan    = p.iscan[(tt >= 10) ? ((tt & 1) ? 2 : 1) : 0];
+    const uint8_t *qm = (tt < 9) ? p.d.qmatrix : nullptr, *iqm = (tt < 9) ? p.d.iqmatrix : nullptr; // IS_2D_TRANSFORM, full_loop.c:1606-1608
     uint32_t satd = 0, eob = 0;
     u64      dres = 0, dpred = 0;
     int32_t *co_out = (p.d.coeff && valid) ? p.d.coeff + (size_t)job * NP : nullptr;
@@ -431,25 +437,36 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
     int32_t *dq_out = (p.d.dqcoeff && valid) ? p.d.dqcoeff + (size_t)job * NP : nullptr;
     for (int rc = l; rc < NP; rc += LW) {
         const int r = rc / WP, c = rc - r * WP, ac = rc != 0;
-        const int32_t co = A[r * PA + c], sign = co < 0 ? -1 : 0, a = (co ^ sign) - sign;
+        const bool kept = pf == 0 || (c < keep_w && r < keep_h);
+        const int32_t co = kept ? A[r * PA + c] : 0, sign = co < 0 ? -1 : 0, a = (co ^ sign) - sign;
         satd += (uint32_t)a;
         int32_t qv = 0, dq = 0;
-        if (p.d.quant_kind == 0) { // svt_aom_quantize_b_c_ii / svt_aom_highbd_quantize_b_c without a quantization matrix
+        const int32_t wt = qm ? qm[rc] : 32, iwt = qm ? iqm[rc] : 32; // AOM_QM_BITS = 5
+        if (p.d.quant_kind == 0) { // svt_aom_quantize_b_c_ii / svt_aom_highbd_quantize_b_c (full_loop.c:29-79,149-198)
             const int32_t zb = log_scale ? ((q.zbin[ac] + (1 << (log_scale - 1))) >> log_scale) : q.zbin[ac];
-            if (a >= zb) {
+            if ((i64)a * wt >= ((i64)zb << 5)) {
                 i64 t = (i64)a + (log_scale ? ((q.round[ac] + (1 << (log_scale - 1))) >> log_scale) : q.round[ac]);
                 if (BD == 8) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
-                t *= 32; // wt = 1 << AOM_QM_BITS
+                t *= wt;
                 qv = (int32_t)(((((t * q.quant[ac]) >> 16) + t) * q.quant_shift[ac]) >> (16 - log_scale + 5));
-                dq = (qv * (int32_t)q.dequant[ac]) >> log_scale;
+                const int32_t deq = ((int32_t)q.dequant[ac] * iwt + 16) >> 5;
+                dq = (qv * deq) >> log_scale;
             }
-        } else { // quantize_fp_helper_c / highbd_quantize_fp_helper_c
+        } else if (!qm) { // quantize_fp_helper_c / highbd_quantize_fp_helper_c without matrices (full_loop.c:282-343,387-452)
             const bool keep = (BD == 8) ? (((i64)a << (1 + log_scale)) >= (int32_t)q.dequant[ac]) : ((a << (1 + log_scale)) >= q.dequant[ac]);
             if (keep) {
                 i64 t = (i64)a + (log_scale ? ((q.round_fp[ac] + (1 << (log_scale - 1))) >> log_scale) : q.round_fp[ac]);
                 if (BD == 8) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
                 qv = (int32_t)((t * q.quant_fp[ac]) >> (16 - log_scale));
                 dq = (qv * (int32_t)q.dequant[ac]) >> log_scale;
+            }
+        } else { // the same helpers' matrix branch
+            if ((i64)a * wt >= ((int32_t)q.dequant[ac] << (5 - (1 + log_scale)))) {
+                i64 t = (i64)a + (log_scale ? ((q.round_fp[ac] + (1 << (log_scale - 1))) >> log_scale) : q.round_fp[ac]);
+                if (BD == 8) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+                qv = (int32_t)((t * q.quant_fp[ac] * wt) >> (16 - log_scale + 5));
+                const int32_t deq = ((int32_t)q.dequant[ac] * iwt + 16) >> 5;
+                dq = (qv * deq) >> log_scale;
             }
         }
         const int32_t qs = (qv ^ sign) - sign, dqs = (dq ^ sign) - sign;
@@ -579,6 +596,7 @@ int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d) {
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "bit_depth %u / quant_kind %u", d->bit_depth, d->quant_kind);
     if (!d->src || !d->pred || !d->jobs || !d->quant_rows || !d->eob || !d->satd || !d->dist_coeff || !d->three_quad_energy || !d->sse)
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the RD batch is null");
+    if ((d->qmatrix == nullptr) != (d->iqmatrix == nullptr)) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "qmatrix and iqmatrix go together");
     hipSetDevice(ctx->device);
     int rc = init_tables(ctx);
     if (rc) return rc;

@@ -38,7 +38,7 @@ def grid_jobs(width, height, stride, tx_size, tx_type=0, quant_row=0, org=0):
     return jobs
 
 
-def run_oracle(desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_recon=True):
+def run_oracle(desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_recon=True, qmatrix=None, iqmatrix=None):
     """CPU oracle mirror of svt_hip_rd_batch on host numpy arrays (test infrastructure; imports oracle/)."""
     import pyoracle
     o = pyoracle.load_oracle()
@@ -54,13 +54,16 @@ def run_oracle(desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_
                         jobs=jobs.ctypes.data, quant_rows=quant_rows.ctypes.data, n_quant_rows=len(quant_rows), **desc_fields)
     for name in out:
         setattr(d, name, out[name].ctypes.data)
+    if qmatrix is not None:
+        qmatrix, iqmatrix = np.ascontiguousarray(qmatrix, np.uint8), np.ascontiguousarray(iqmatrix, np.uint8)
+        d.qmatrix, d.iqmatrix = qmatrix.ctypes.data, iqmatrix.ctypes.data
     assert o.orc_rd_batch(C.byref(d)) == 0
     if want_recon:
         out["recon"] = recon
     return out
 
 
-def run_hip(ctx, desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_recon=True):
+def run_hip(ctx, desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_recon=True, qmatrix=None, iqmatrix=None):
     """Runs svt_hip_rd_batch on device copies of the inputs; returns numpy results."""
     import torch
     ts = desc_fields["tx_size"]
@@ -77,6 +80,9 @@ def run_hip(ctx, desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, wan
                         jobs=t_jobs.data_ptr(), quant_rows=t_q.data_ptr(), n_quant_rows=len(quant_rows), **desc_fields)
     for name, t in outs.items():
         setattr(d, name, t.data_ptr())
+    if qmatrix is not None:
+        t_qm, t_iqm = dev(np.asarray(qmatrix, np.uint8)), dev(np.asarray(iqmatrix, np.uint8))
+        d.qmatrix, d.iqmatrix = t_qm.data_ptr(), t_iqm.data_ptr()
     torch.cuda.synchronize()
     ctx.check(api.lib().svt_hip_rd_batch(ctx._h, C.byref(d)), "svt_hip_rd_batch")
     ctx.sync()

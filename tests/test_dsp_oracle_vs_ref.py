@@ -197,3 +197,30 @@ def test_fwd_and_inv_txfm2d(ref, oracle, ts):
             rb = pred.copy()
             oracle.orc_inv_txfm2d_add(p(co), p(pred), C.c_int32(stride), p(rb), C.c_int32(stride), tt, ts, bd)
             assert np.array_equal(ra, rb), ("inv", tt, bd, pat)
+
+
+TX_NAMES = ["4x4", "8x8", "16x16", "32x32", "64x64", "4x8", "8x4", "8x16", "16x8", "16x32", "32x16", "32x64", "64x32", "4x16", "16x4", "8x32", "32x8",
+            "16x64", "64x16"]
+
+
+@pytest.mark.parametrize("ts", range(19))
+def test_partial_frequency_transforms_are_masked_full_transforms(ref, oracle, ts):
+    """av1_estimate_transform_N2 / _N4 (transforms.c:2633-2948): the reference's pruned forward transforms equal the full
+    transform with everything outside the top-left quarter / sixteenth zeroed -- which is how rd_oracle.c and the HIP
+    kernel implement pf_shape."""
+    from txfm_cases import valid_types
+    rng = np.random.default_rng(ts)
+    W, H = TX_W[ts], TX_H[ts]
+    nm = TX_NAMES[ts]
+    for shape, sh in (("N2", 1), ("N4", 2)):
+        fn = getattr(ref, f"svt_aom_transform_two_d_{nm}_{shape}_c" if W == H else f"svt_av1_fwd_txfm2d_{nm}_{shape}_c")
+        for tt in valid_types(ts):
+            for bd in (8, 10):
+                res = rng.integers(-(1 << bd) + 1, 1 << bd, (H, W + 3)).astype(np.int16)
+                full, part = np.zeros(W * H, np.int32), np.zeros(W * H, np.int32)
+                oracle.orc_fwd_txfm2d(p(res), p(full), C.c_uint32(W + 3), C.c_int(tt), C.c_int(ts))
+                fn(p(res), p(part), C.c_uint32(W + 3), C.c_int(tt), C.c_uint8(bd))
+                f2 = full.reshape(H, W).copy()
+                f2[H >> sh:, :] = 0
+                f2[:, W >> sh:] = 0
+                assert np.array_equal(f2.reshape(-1), part), (nm, shape, tt, bd)

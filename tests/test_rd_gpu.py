@@ -69,3 +69,25 @@ def test_rd_batch_rejects_bad_descriptors(hip_ctx):
     assert api.lib().svt_hip_rd_batch(hip_ctx._h, C.byref(d)) == 2
     d = abi.RdBatchDesc(n_jobs=4, bit_depth=8, tx_size=40)
     assert api.lib().svt_hip_rd_batch(hip_ctx._h, C.byref(d)) == 2
+
+
+@pytest.mark.parametrize("tx_size", [0, 1, 2, 3, 4, 6, 9, 12, 13, 17, 18])
+def test_partial_frequency_shapes_and_quantization_matrices(hip_ctx, tx_size):
+    """pf_shape (N2 / N4 / ONLY_DC) per job and a quantization matrix per batch, both quantizers, 8 / 10 bit."""
+    rng = np.random.default_rng(300 + tx_size)
+    rows = np.stack([rd.quant_row_from_step(8, 10), rd.quant_row_from_step(60, 75)])
+    npk = min(abi.TX_W[tx_size], 32) * min(abi.TX_H[tx_size], 32)
+    for bd in (8, 10):
+        src, pred = _planes(rng, bd, "smooth")
+        for quant_kind in (0, 1):
+            for use_qm in (False, True):
+                jobs = rd.grid_jobs(192, 128, 192, tx_size)
+                jobs["tx_type"] = rng.choice(valid_types(tx_size), len(jobs))
+                jobs["quant_row"] = rng.integers(0, 2, len(jobs))
+                jobs["pf_shape"] = rng.integers(0, 4, len(jobs))
+                qm = rng.integers(16, 256, npk).astype(np.uint8) if use_qm else None   # AV1 matrices: 32 = unit weight
+                iqm = rng.integers(16, 256, npk).astype(np.uint8) if use_qm else None
+                f = dict(bit_depth=bd, quant_kind=quant_kind, tx_size=tx_size, src_stride=192, pred_stride=192)
+                want = rd.run_oracle(f, src, pred, jobs, rows, qmatrix=qm, iqmatrix=iqm)
+                got = rd.run_hip(hip_ctx, f, src, pred, jobs, rows, qmatrix=qm, iqmatrix=iqm)
+                _check(want, got, (tx_size, bd, quant_kind, use_qm))
