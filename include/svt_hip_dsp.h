@@ -79,14 +79,16 @@ int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d);
  *   svt_nxm_sad_kernel_helper_c / svt_aom_sad_16b_kernel_c          (C_DEFAULT/compute_sad_c.c:20-56,209)
  *   svt_spatial_full_distortion_kernel_c / svt_full_distortion_kernel16_bits_c / svt_aom_sse_c
  *                                                                   (C_DEFAULT/picture_operators_c.c:65-83, Codec/pic_operators.c:174-197)
- *   svt_aom_variance{W}x{H}_c                                       (C_DEFAULT/variance.c:256-296)
+ *   svt_aom_variance{W}x{H}_c, svt_aom_sub_pixel_variance{W}x{H}_c  (C_DEFAULT/variance.c:256-318)
  *   hadamard_path_c = residual -> svt_aom_hadamard_NxN -> svt_aom_satd over <= 32x32 tiles
  *                                                                   (Codec/enc_mode_config.c:2151-2217)
  *   svt_psy_distortion / svt_psy_distortion_hbd / get_svt_psy_full_dist  (Codec/psy_rd.c:135-293)                           */
 typedef struct SvtHipBlockJob {
     uint32_t src_offset, ref_offset; /* sample offsets of the block's top-left sample in the two planes */
     uint8_t  width, height;          /* 1..128 */
-    uint8_t  reserved[2];
+    uint8_t  subpel_x, subpel_y;     /* 0..7: the src block is first interpolated at this 1/8-sample phase with the 2-tap bilinear
+                                      * filters of svt_aom_sub_pixel_variance{W}x{H}_c (C_DEFAULT/variance.c:28-75,308-318;
+                                      * filter.h:39-48): horizontal pass on height+1 rows, then vertical.  (0,0) = src as is */
 } SvtHipBlockJob;
 
 typedef struct SvtHipBlockStatsDesc {

@@ -40,6 +40,17 @@ SVT_HIP_DECL_VAR(32, 8) SVT_HIP_DECL_VAR(32, 16) SVT_HIP_DECL_VAR(32, 32) SVT_HI
 SVT_HIP_DECL_VAR(64, 64) SVT_HIP_DECL_VAR(64, 128) SVT_HIP_DECL_VAR(128, 64) SVT_HIP_DECL_VAR(128, 128)
 #undef SVT_HIP_DECL_VAR
 
+/* svt_aom_sub_pixel_variance{W}x{H} (aom_dsp_rtcd.h; C_DEFAULT/variance.c:308-318): xoffset / yoffset in 1/8 samples */
+unsigned int svt_aom_sub_pixel_variance_hip(const uint8_t *src, int src_stride, int xoffset, int yoffset, const uint8_t *ref, int ref_stride, int width,
+                                            int height, unsigned int *sse);
+#define SVT_HIP_DECL_SPVAR(W, H) \
+    unsigned int svt_aom_sub_pixel_variance##W##x##H##_hip(const uint8_t *src, int src_stride, int xoffset, int yoffset, const uint8_t *ref, int ref_stride, unsigned int *sse);
+SVT_HIP_DECL_SPVAR(4, 4) SVT_HIP_DECL_SPVAR(4, 8) SVT_HIP_DECL_SPVAR(4, 16) SVT_HIP_DECL_SPVAR(8, 4) SVT_HIP_DECL_SPVAR(8, 8) SVT_HIP_DECL_SPVAR(8, 16)
+SVT_HIP_DECL_SPVAR(8, 32) SVT_HIP_DECL_SPVAR(16, 4) SVT_HIP_DECL_SPVAR(16, 8) SVT_HIP_DECL_SPVAR(16, 16) SVT_HIP_DECL_SPVAR(16, 32) SVT_HIP_DECL_SPVAR(16, 64)
+SVT_HIP_DECL_SPVAR(32, 8) SVT_HIP_DECL_SPVAR(32, 16) SVT_HIP_DECL_SPVAR(32, 32) SVT_HIP_DECL_SPVAR(32, 64) SVT_HIP_DECL_SPVAR(64, 16) SVT_HIP_DECL_SPVAR(64, 32)
+SVT_HIP_DECL_SPVAR(64, 64) SVT_HIP_DECL_SPVAR(64, 128) SVT_HIP_DECL_SPVAR(128, 64) SVT_HIP_DECL_SPVAR(128, 128)
+#undef SVT_HIP_DECL_SPVAR
+
 /* svt_aom_sse (aom_dsp_rtcd.h:53), svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (common_dsp_rtcd.h:164-168) */
 int64_t  svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height);
 uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,

@@ -124,7 +124,7 @@ def gen_block_stats():
         src[:64, :64] = (1 << bd) - 1; refp[:64, :64] = 0          # extremes (VarianceTest.cc / SadTest.cc patterns)
         src[64:128, :64] = 0; refp[64:128, :64] = (1 << bd) - 1
         jobs = stats.random_jobs(rng, W, H, 160)
-        jobs[0] = (0, 0, 64, 64, (0, 0)); jobs[1] = (64 * W, 64 * W, 64, 64, (0, 0)); jobs[2] = (0, 64 * W, 32, 32, (0, 0))
+        jobs[0] = (0, 0, 64, 64, 0, 0); jobs[1] = (64 * W, 64 * W, 64, 64, 0, 0); jobs[2] = (0, 64 * W, 32, 32, 0, 0)
         exp = {name: np.zeros(len(jobs), dtype=d) for name, d in abi.STATS_OUT_FIELDS + abi.PSY_OUT_FIELDS}
         ref.svt_psy_distortion.restype = ref.svt_psy_distortion_hbd.restype = ref.get_svt_psy_full_dist.restype = C.c_uint64
         for j, jb in enumerate(jobs):
@@ -154,6 +154,22 @@ def gen_block_stats():
                 exp["var_sse"][j] = vs.value
         out.update({f"src{bd}": src, f"ref{bd}": refp, f"jobs{bd}": jobs.view(np.uint8).reshape(len(jobs), -1)})
         out.update({f"{k}{bd}": v for k, v in exp.items()})
+    # sub-pixel variance (8-bit planes of above): AV1 variance shapes x all 64 phases, from svt_aom_sub_pixel_variance{W}x{H}_c
+    rng = np.random.default_rng(208)
+    src, refp = out["src8"], out["ref8"]
+    W, H = src.shape[1], src.shape[0]
+    sizes = [sz for sz in abi.VARIANCE_SIZES if sz[0] < W and sz[1] < H]
+    sp = stats.random_jobs(rng, W, H, 320, sizes=sizes, subpel=True)
+    sp["subpel_x"][:64] = np.arange(64) % 8; sp["subpel_y"][:64] = np.arange(64) // 8
+    sp_var, sp_sse = np.zeros(len(sp), np.uint32), np.zeros(len(sp), np.uint32)
+    for j, jb in enumerate(sp):
+        w, h = int(jb["width"]), int(jb["height"])
+        s = src.reshape(-1)[int(jb["src_offset"]):]
+        r = refp.reshape(-1)[int(jb["ref_offset"]):]
+        vs = C.c_uint32()
+        sp_var[j] = getattr(ref, f"svt_aom_sub_pixel_variance{w}x{h}_c")(ptr(s), W, int(jb["subpel_x"]), int(jb["subpel_y"]), ptr(r), W, C.byref(vs)) & 0xFFFFFFFF
+        sp_sse[j] = vs.value
+    out.update(sp_jobs=sp.view(np.uint8).reshape(len(sp), -1), sp_variance=sp_var, sp_var_sse=sp_sse)
     np.savez_compressed(os.path.join(OUT, "block_stats.npz"), **out)
     print("wrote block_stats")
 

@@ -133,6 +133,34 @@ uint64_t orc_psy_distortion(const void *input, uint32_t input_stride, const void
     return is16 ? total << 2 : total >> 1;
 }
 
+/* The 2-tap bilinear interpolation in front of svt_aom_sub_pixel_variance{W}x{H}_c (C_DEFAULT/variance.c:28-75,308-318):
+ * horizontal pass on h + 1 rows into 16-bit, vertical pass back to the pixel type; taps {128 - 16k, 16k} (filter.h:39-48),
+ * rounding shift by FILTER_BITS = 7.  Samples are widened to uint16 so that one routine serves both bit depths. */
+static void bilinear_block(const void *src, int is16, uint32_t stride, int w, int h, int xo, int yo, uint16_t *out /* [h][w] */) {
+    uint16_t *mid = malloc(sizeof(uint16_t) * (size_t)(h + 1) * w);
+    const int fx0 = 128 - 16 * xo, fx1 = 16 * xo, fy0 = 128 - 16 * yo, fy1 = 16 * yo;
+    for (int y = 0; y < h + 1; y++)
+        for (int x = 0; x < w; x++) {
+            const int a0 = is16 ? ((const uint16_t *)src)[(size_t)y * stride + x] : ((const uint8_t *)src)[(size_t)y * stride + x];
+            /* with a zero second tap the reference still multiplies the neighbour by 0: no read is needed for the value */
+            const int a1 = fx1 ? (is16 ? ((const uint16_t *)src)[(size_t)y * stride + x + 1] : ((const uint8_t *)src)[(size_t)y * stride + x + 1]) : 0;
+            mid[y * w + x] = (uint16_t)((a0 * fx0 + a1 * fx1 + 64) >> 7);
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) out[y * w + x] = (uint16_t)((mid[y * w + x] * fy0 + (fy1 ? mid[(y + 1) * w + x] * fy1 : 0) + 64) >> 7);
+    free(mid);
+}
+
+uint32_t orc_sub_pixel_variance8(const uint8_t *a, int a_stride, int xoffset, int yoffset, const uint8_t *b, int b_stride, int w, int h, uint32_t *sse) {
+    uint16_t *t16 = malloc(sizeof(uint16_t) * (size_t)w * h);
+    uint8_t  *t8  = malloc((size_t)w * h);
+    bilinear_block(a, 0, (uint32_t)a_stride, w, h, xoffset, yoffset, t16);
+    for (int i = 0; i < w * h; i++) t8[i] = (uint8_t)t16[i];
+    const uint32_t v = orc_variance8(t8, w, b, b_stride, w, h, sse);
+    free(t16); free(t8);
+    return v;
+}
+
 int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
     if (!d || (d->bit_depth != 8 && d->bit_depth != 10) || !d->src || !d->ref || !d->jobs) return 2;
     if (d->satd && d->bit_depth != 8) return 2;
@@ -141,25 +169,37 @@ int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
         const int w = jb.width, h = jb.height;
         uint32_t sad, var, vsse;
         uint64_t sse;
+        const int subpel = (jb.subpel_x | jb.subpel_y) & 7;
+        uint32_t  s_stride = d->src_stride;
+        uint16_t *f16 = NULL;
+        uint8_t  *f8  = NULL;
+        if (subpel) { /* every statistic then sees the interpolated source block */
+            f16 = malloc(sizeof(uint16_t) * (size_t)w * h);
+            bilinear_block(d->bit_depth == 8 ? (const void *)((const uint8_t *)d->src + jb.src_offset) : (const void *)((const uint16_t *)d->src + jb.src_offset),
+                           d->bit_depth != 8, d->src_stride, w, h, jb.subpel_x & 7, jb.subpel_y & 7, f16);
+            if (d->bit_depth == 8) { f8 = malloc((size_t)w * h); for (int i = 0; i < w * h; i++) f8[i] = (uint8_t)f16[i]; }
+            s_stride = (uint32_t)w;
+        }
         if (d->bit_depth == 8) {
-            const uint8_t *s = (const uint8_t *)d->src + jb.src_offset, *r = (const uint8_t *)d->ref + jb.ref_offset;
-            sad = orc_nxm_sad(s, d->src_stride, r, d->ref_stride, (uint32_t)h, (uint32_t)w);
-            sse = orc_spatial_sse8(s, 0, d->src_stride, r, 0, d->ref_stride, (uint32_t)w, (uint32_t)h);
-            var = orc_variance8(s, (int)d->src_stride, r, (int)d->ref_stride, w, h, &vsse);
+            const uint8_t *s = subpel ? f8 : (const uint8_t *)d->src + jb.src_offset, *r = (const uint8_t *)d->ref + jb.ref_offset;
+            sad = orc_nxm_sad(s, s_stride, r, d->ref_stride, (uint32_t)h, (uint32_t)w);
+            sse = orc_spatial_sse8(s, 0, s_stride, r, 0, d->ref_stride, (uint32_t)w, (uint32_t)h);
+            var = orc_variance8(s, (int)s_stride, r, (int)d->ref_stride, w, h, &vsse);
             if (d->satd) {
                 const int sq = w == h && (w == 4 || w == 8 || w == 16 || w == 32 || w == 64 || w == 128);
-                d->satd[j] = sq ? orc_hadamard_path(s, d->src_stride, r, d->ref_stride, (uint32_t)w) : 0;
+                d->satd[j] = sq ? orc_hadamard_path(s, s_stride, r, d->ref_stride, (uint32_t)w) : 0;
             }
         } else {
-            const uint16_t *s = (const uint16_t *)d->src + jb.src_offset, *r = (const uint16_t *)d->ref + jb.ref_offset;
-            sad = orc_sad_16b(s, d->src_stride, r, d->ref_stride, (uint32_t)h, (uint32_t)w);
-            sse = orc_spatial_sse16(s, 0, d->src_stride, r, 0, d->ref_stride, (uint32_t)w, (uint32_t)h);
-            var = orc_variance16(s, (int)d->src_stride, r, (int)d->ref_stride, w, h, &vsse);
+            const uint16_t *s = subpel ? f16 : (const uint16_t *)d->src + jb.src_offset, *r = (const uint16_t *)d->ref + jb.ref_offset;
+            sad = orc_sad_16b(s, s_stride, r, d->ref_stride, (uint32_t)h, (uint32_t)w);
+            sse = orc_spatial_sse16(s, 0, s_stride, r, 0, d->ref_stride, (uint32_t)w, (uint32_t)h);
+            var = orc_variance16(s, (int)s_stride, r, (int)d->ref_stride, w, h, &vsse);
         }
         if (d->psy_energy || d->psy_dist) {
             if ((w & 3) || (h & 3)) return 2;
             const size_t bpp = d->bit_depth == 8 ? 1 : 2;
-            const uint64_t e = orc_psy_distortion((const uint8_t *)d->src + (size_t)jb.src_offset * bpp, d->src_stride,
+            const void *ps = subpel ? (d->bit_depth == 8 ? (const void *)f8 : (const void *)f16) : (const void *)((const uint8_t *)d->src + (size_t)jb.src_offset * bpp);
+            const uint64_t e = orc_psy_distortion(ps, s_stride,
                                                   (const uint8_t *)d->ref + (size_t)jb.ref_offset * bpp, d->ref_stride, (uint32_t)w, (uint32_t)h, d->bit_depth != 8);
             if (d->psy_energy) d->psy_energy[j] = e;
             if (d->psy_dist) d->psy_dist[j] = (uint64_t)((double)e * d->psy_rd); /* get_svt_psy_full_dist, psy_rd.c:277-293 */
@@ -168,6 +208,7 @@ int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
         if (d->sse) d->sse[j] = sse;
         if (d->variance) d->variance[j] = var;
         if (d->var_sse) d->var_sse[j] = vsse;
+        free(f16); free(f8);
     }
     return 0;
 }

@@ -144,7 +144,7 @@ RD_OUT_FIELDS = [("eob", "<u2", 1), ("satd", "<u4", 1), ("dist_coeff", "<u8", 2)
 
 
 class BlockJob(C.Structure):
-    _fields_ = [("src_offset", C.c_uint32), ("ref_offset", C.c_uint32), ("width", C.c_uint8), ("height", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+    _fields_ = [("src_offset", C.c_uint32), ("ref_offset", C.c_uint32), ("width", C.c_uint8), ("height", C.c_uint8), ("subpel_x", C.c_uint8), ("subpel_y", C.c_uint8)]
 
 
 class BlockStatsDesc(C.Structure):
@@ -154,7 +154,7 @@ class BlockStatsDesc(C.Structure):
                 ("psy_rd", C.c_double), ("psy_energy", C.c_void_p), ("psy_dist", C.c_void_p)]
 
 
-BLOCK_JOB_DTYPE = [("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("reserved", "u1", (2,))]
+BLOCK_JOB_DTYPE = [("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("subpel_x", "u1"), ("subpel_y", "u1")]
 STATS_OUT_FIELDS = [("sad", "<u4"), ("sse", "<u8"), ("variance", "<u4"), ("var_sse", "<u4"), ("satd", "<u4")]
 PSY_OUT_FIELDS = [("psy_energy", "<u8"), ("psy_dist", "<u8")]
 VARIANCE_SIZES = [(4, 4), (4, 8), (4, 16), (8, 4), (8, 8), (8, 16), (8, 32), (16, 4), (16, 8), (16, 16), (16, 32), (16, 64), (32, 8), (32, 16),

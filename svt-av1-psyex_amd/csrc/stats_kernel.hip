@@ -124,6 +124,26 @@ __device__ void hadamard_tile(HadLds &L, int n, int lane) {
     }
 }
 
+// A block of a plane, optionally seen through the 2-tap bilinear interpolation of svt_aom_sub_pixel_variance{W}x{H}_c
+// (C_DEFAULT/variance.c:28-75,308-318; taps {128 - 16k, 16k}, filter.h:39-48): horizontal pass into 16 bit, vertical pass
+// back to the pixel range, each with a rounding shift by FILTER_BITS = 7.  Evaluated on the fly (4 cached reads per
+// sample); a neighbour is only read when its tap is non-zero.
+template <typename Pix> struct View {
+    const Pix *p;
+    uint32_t   stride;
+    int        fx1, fy1; // second taps (0 = no interpolation in that direction)
+    __device__ __forceinline__ int at(int y, int x) const {
+        const Pix *q = p + (size_t)y * stride + x;
+        if ((fx1 | fy1) == 0) return (int)q[0];
+        const int fx0 = 128 - fx1, fy0 = 128 - fy1;
+        const int m0 = ((int)q[0] * fx0 + (fx1 ? (int)q[1] * fx1 : 0) + 64) >> 7;
+        if (!fy1) return (m0 * fy0 + 64) >> 7;
+        const int m1 = ((int)q[stride] * fx0 + (fx1 ? (int)q[stride + 1] * fx1 : 0) + 64) >> 7;
+        return (m0 * fy0 + m1 * fy1 + 64) >> 7;
+    }
+    __device__ __forceinline__ View sub(int y, int x) const { View v = *this; v.p = p + (size_t)y * stride + x; return v; }
+};
+
 // ---- PSYEX psy-RD energy (Codec/psy_rd.c:64-274) -----------------------------------------------------------------
 // 8-bit: the reference's packed 2 x 16-bit Hadamard never overflows a half on pixel data, so it equals the plain
 // unnormalised 2-D Hadamard.  10-bit: its 4-point butterflies keep 32-bit temporaries, so only the low half of the
@@ -145,7 +165,7 @@ __device__ __forceinline__ u64 abs_halves(u64 a) { const u64 m = (a >> 31) & 0x1
 __device__ __forceinline__ u64 fold_halves(u64 b) { return (uint32_t)b + (b >> 32); }
 
 // energy of one n x n tile (n = 8 or 4) of plane p: Hadamard sum - (sum of pixels >> 2)
-template <typename Pix> __device__ int32_t psy_tile_energy(const Pix *p, uint32_t stride, int n) {
+template <typename Pix> __device__ int32_t psy_tile_energy(const View<Pix> &pv, int n) {
     i64 sum = 0, had;
     if (sizeof(Pix) == 1) {
         int32_t m[8][8];
@@ -153,7 +173,7 @@ template <typename Pix> __device__ int32_t psy_tile_energy(const Pix *p, uint32_
 #pragma unroll
             for (int y = 0; y < 8; y++) {
 #pragma unroll
-                for (int x = 0; x < 8; x++) { m[y][x] = (int32_t)p[(size_t)y * stride + x]; sum += m[y][x]; }
+                for (int x = 0; x < 8; x++) { m[y][x] = (int32_t)pv.at(y, x); sum += m[y][x]; }
                 had8_inplace(m[y]);
             }
             i64 acc = 0;
@@ -173,7 +193,7 @@ template <typename Pix> __device__ int32_t psy_tile_energy(const Pix *p, uint32_
 #pragma unroll
             for (int y = 0; y < 4; y++) {
 #pragma unroll
-                for (int x = 0; x < 4; x++) { q[y][x] = (int32_t)p[(size_t)y * stride + x]; sum += q[y][x]; }
+                for (int x = 0; x < 4; x++) { q[y][x] = (int32_t)pv.at(y, x); sum += q[y][x]; }
                 const int32_t a = q[y][0] + q[y][1], b = q[y][0] - q[y][1], c = q[y][2] + q[y][3], d = q[y][2] - q[y][3];
                 q[y][0] = a + c; q[y][1] = b + d; q[y][2] = a - c; q[y][3] = b - d;
             }
@@ -192,7 +212,7 @@ template <typename Pix> __device__ int32_t psy_tile_energy(const Pix *p, uint32_
             for (int i = 0; i < 8; i++) {
                 int32_t r[8];
 #pragma unroll
-                for (int x = 0; x < 8; x++) { r[x] = (int32_t)p[(size_t)i * stride + x]; sum += r[x]; }
+                for (int x = 0; x < 8; x++) { r[x] = (int32_t)pv.at(i, x); sum += r[x]; }
                 bfly_low(t[i], pack32(r[0], r[1]), pack32(r[2], r[3]), pack32(r[4], r[5]), pack32(r[6], r[7]));
             }
 #pragma unroll
@@ -210,7 +230,7 @@ template <typename Pix> __device__ int32_t psy_tile_energy(const Pix *p, uint32_
             for (int i = 0; i < 4; i++) {
                 int32_t r[4];
 #pragma unroll
-                for (int x = 0; x < 4; x++) { r[x] = (int32_t)p[(size_t)i * stride + x]; sum += r[x]; }
+                for (int x = 0; x < 4; x++) { r[x] = (int32_t)pv.at(i, x); sum += r[x]; }
                 const u64 b0 = pack32(r[0], r[1]), b1 = pack32(r[2], r[3]);
                 t[i][0] = b0 + b1; t[i][1] = b0 - b1;
             }
@@ -236,15 +256,15 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
     const uint32_t job  = blockIdx.x;
     const SvtHipBlockJob jb = p.d.jobs[job];
     const int w = jb.width, h = jb.height;
-    const Pix *src = static_cast<const Pix *>(p.d.src) + jb.src_offset;
-    const Pix *ref = static_cast<const Pix *>(p.d.ref) + jb.ref_offset;
+    const View<Pix> src = {static_cast<const Pix *>(p.d.src) + jb.src_offset, p.d.src_stride, 16 * (jb.subpel_x & 7), 16 * (jb.subpel_y & 7)};
+    const View<Pix> ref = {static_cast<const Pix *>(p.d.ref) + jb.ref_offset, p.d.ref_stride, 0, 0};
     uint32_t sad = 0, sq32 = 0;
     int32_t  sum = 0;
     u64      sse = 0;
     const float rw = __builtin_amdgcn_rcpf((float)w);
     for (int i = lane; i < w * h; i += 64) {
         const int r = (int)(((float)i + 0.5f) * rw), c = i - r * w; // exact for i < 2^21
-        const int d = (int)src[(size_t)r * p.d.src_stride + c] - (int)ref[(size_t)r * p.d.ref_stride + c];
+        const int d = src.at(r, c) - ref.at(r, c);
         sad += (uint32_t)(d < 0 ? -d : d);
         sum += d;
         sq32 += (uint32_t)(d * d);
@@ -268,8 +288,7 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
                 for (int tx = 0; tx < w; tx += n) {
                     for (int i = lane; i < n * n; i += 64) {
                         const int r = i / n, c = i - r * n;
-                        L.res[r * kResPitch + c] = (int16_t)((int16_t)src[(size_t)(ty + r) * p.d.src_stride + tx + c] -
-                                                             (int16_t)ref[(size_t)(ty + r) * p.d.ref_stride + tx + c]);
+                        L.res[r * kResPitch + c] = (int16_t)((int16_t)src.at(ty + r, tx + c) - (int16_t)ref.at(ty + r, tx + c));
                     }
                     __syncthreads();
                     hadamard_tile(L, n, lane);
@@ -285,8 +304,8 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         u64 total = 0;
         for (int t = lane; t < nt; t += 64) {
             const int ty = t / ntx, tx = t - ty * ntx;
-            const int32_t a = psy_tile_energy<Pix>(src + (size_t)(ty * n) * p.d.src_stride + tx * n, p.d.src_stride, n);
-            const int32_t b = psy_tile_energy<Pix>(ref + (size_t)(ty * n) * p.d.ref_stride + tx * n, p.d.ref_stride, n);
+            const int32_t a = psy_tile_energy<Pix>(src.sub(ty * n, tx * n), n);
+            const int32_t b = psy_tile_energy<Pix>(ref.sub(ty * n, tx * n), n);
             total += (u64)(a > b ? a - b : b - a);
         }
         total = wave_sum(total);
@@ -417,19 +436,20 @@ struct StatsOut { uint32_t sad, variance, var_sse, satd; u64 sse, psy_energy, ps
 
 // one (src, ref) block through block_stats_kernel
 StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t ref_stride, int w, int h, int bit_depth, bool want_satd,
-                    bool want_psy = false, double psy_rd = 0.0) {
+                    bool want_psy = false, double psy_rd = 0.0, int xo = 0, int yo = 0) {
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
     const size_t bpp = bit_depth == 8 ? 1 : 2;
-    const size_t sb = align256(((size_t)h - 1) * src_stride * bpp + (size_t)w * bpp), rb = align256(((size_t)h - 1) * ref_stride * bpp + (size_t)w * bpp);
+    const int sh = h + (yo ? 1 : 0), sw = w + (xo ? 1 : 0); // the interpolation reads one more row / column
+    const size_t sb = align256(((size_t)sh - 1) * src_stride * bpp + (size_t)sw * bpp), rb = align256(((size_t)h - 1) * ref_stride * bpp + (size_t)w * bpp);
     uint8_t *base = leaf_scratch(ctx, sb + rb + 512);
     uint8_t *d_src = base, *d_ref = base + sb, *d_job = d_ref + rb, *d_out = d_job + 256;
-    upload_rows(ctx, d_src, src, src_stride * bpp, h, (size_t)w * bpp);
+    upload_rows(ctx, d_src, src, src_stride * bpp, sh, (size_t)sw * bpp);
     upload_rows(ctx, d_ref, ref, ref_stride * bpp, h, (size_t)w * bpp);
     SvtHipBlockJob job;
     memset(&job, 0, sizeof(job));
-    job.width = (uint8_t)w; job.height = (uint8_t)h;
+    job.width = (uint8_t)w; job.height = (uint8_t)h; job.subpel_x = (uint8_t)xo; job.subpel_y = (uint8_t)yo;
     leaf_check(ctx, hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
     SvtHipBlockStatsDesc d;
     memset(&d, 0, sizeof(d));
@@ -500,9 +520,20 @@ unsigned int svt_aom_variance_hip(const uint8_t *src, int src_stride, const uint
     return o.variance;
 }
 
+unsigned int svt_aom_sub_pixel_variance_hip(const uint8_t *src, int src_stride, int xoffset, int yoffset, const uint8_t *ref, int ref_stride, int width,
+                                            int height, unsigned int *sse) {
+    const StatsOut o = leaf_stats(src, (size_t)src_stride, ref, (size_t)ref_stride, width, height, 8, false, false, 0.0, xoffset & 7, yoffset & 7);
+    *sse = o.var_sse;
+    return o.variance;
+}
+
 #define SVT_HIP_VAR(W, H)                                                                                                             \
     unsigned int svt_aom_variance##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, unsigned int *sse) { \
         return svt_aom_variance_hip(src, src_stride, ref, ref_stride, W, H, sse);                                                       \
+    }                                                                                                                                 \
+    unsigned int svt_aom_sub_pixel_variance##W##x##H##_hip(const uint8_t *src, int src_stride, int xoffset, int yoffset, const uint8_t *ref, \
+                                                           int ref_stride, unsigned int *sse) {                                      \
+        return svt_aom_sub_pixel_variance_hip(src, src_stride, xoffset, yoffset, ref, ref_stride, W, H, sse);                           \
     }
 SVT_HIP_VAR(4, 4) SVT_HIP_VAR(4, 8) SVT_HIP_VAR(4, 16) SVT_HIP_VAR(8, 4) SVT_HIP_VAR(8, 8) SVT_HIP_VAR(8, 16) SVT_HIP_VAR(8, 32)
 SVT_HIP_VAR(16, 4) SVT_HIP_VAR(16, 8) SVT_HIP_VAR(16, 16) SVT_HIP_VAR(16, 32) SVT_HIP_VAR(16, 64) SVT_HIP_VAR(32, 8) SVT_HIP_VAR(32, 16)

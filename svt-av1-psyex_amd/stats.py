@@ -6,7 +6,7 @@ import numpy as np
 from . import abi
 
 
-def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False):
+def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False, subpel=False):
     """n block jobs with AV1 block shapes at random positions inside a plane_w x plane_h plane."""
     sizes = sizes or [(w, h) for w in (4, 8, 16, 32, 64, 128) for h in (4, 8, 16, 32, 64, 128) if max(w, h) <= 4 * min(w, h)]
     if square_only:
@@ -15,9 +15,12 @@ def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False):
     for i in range(n):
         w, h = sizes[rng.integers(len(sizes))]
         w, h = min(w, plane_w), min(h, plane_h)
-        x0, y0 = rng.integers(0, plane_w - w + 1), rng.integers(0, plane_h - h + 1)
+        x0, y0 = rng.integers(0, plane_w - w + 1 - int(subpel)), rng.integers(0, plane_h - h + 1 - int(subpel))  # sub-pel reads one more row / column
         x1, y1 = rng.integers(0, plane_w - w + 1), rng.integers(0, plane_h - h + 1)
-        jobs[i] = (y0 * plane_w + x0, y1 * plane_w + x1, w, h, (0, 0))
+        jobs[i] = (y0 * plane_w + x0, y1 * plane_w + x1, w, h, 0, 0)
+    if subpel:
+        jobs["subpel_x"] = rng.integers(0, 8, n)
+        jobs["subpel_y"] = rng.integers(0, 8, n)
     return jobs
 
 

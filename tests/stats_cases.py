@@ -27,3 +27,10 @@ def mismatches(exp, got, bd):
             i = int(np.flatnonzero(exp[name] != got[name])[0])
             bad.append(f"{name}: first mismatch at job {i}: {exp[name][i]} vs {got[name][i]}")
     return bad
+
+
+def load_subpel_fixture():
+    """8-bit planes + jobs with sub-pel phases; expected variance / var_sse from svt_aom_sub_pixel_variance{W}x{H}_c."""
+    z = np.load(GOLDEN)
+    jobs = np.ascontiguousarray(z["sp_jobs"]).view(abi.BLOCK_JOB_DTYPE).reshape(-1)
+    return z["src8"], z["ref8"], jobs, {"variance": z["sp_variance"], "var_sse": z["sp_var_sse"]}

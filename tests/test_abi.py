@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/*.h but not exported by libsvthip.so: {missing}"
     assert len(declared_symbols()) >= 30
     # the variance entries are declared through a macro
-    missing = [f"svt_aom_variance{w}x{h}_hip" for (w, h) in abi.VARIANCE_SIZES if not hasattr(L, f"svt_aom_variance{w}x{h}_hip")]
+    missing = [f"svt_aom_{k}variance{w}x{h}_hip" for (w, h) in abi.VARIANCE_SIZES for k in ("", "sub_pixel_") if not hasattr(L, f"svt_aom_{k}variance{w}x{h}_hip")]
     assert not missing, missing
 
 

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from stats_cases import PSY_RD, load_fixture, mismatches
+from stats_cases import PSY_RD, load_fixture, load_subpel_fixture, mismatches
 from svt_av1_psyex_amd import abi, api, stats
 
 pytestmark = pytest.mark.gpu
@@ -150,3 +150,31 @@ def test_leaf_psy_distortion(leaf, oracle):
             a2 = a16.reshape(-1)[1:]; b2 = b16.reshape(-1)[2:]
             want = int(float(oracle.orc_psy_distortion(p(a2), C.c_uint32(w + 3), p(b2), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(hh), C.c_int(1))) * 0.75)
             assert got == want, (w, h)
+
+
+def test_sub_pixel_variance_fixture_and_oracle(hip_ctx, oracle):
+    src, ref, jobs, exp = load_subpel_fixture()
+    got = stats.run_hip(hip_ctx, src, ref, jobs, 8, satd=False)
+    for k in exp:
+        assert np.array_equal(exp[k], got[k]), k
+    # every statistic of interpolated blocks, both bit depths, against the oracle
+    for bd in (8, 10):
+        rng = np.random.default_rng(60 + bd)
+        W, H = 320, 200
+        dt = np.uint8 if bd == 8 else np.uint16
+        s = rng.integers(0, 1 << bd, (H, W)).astype(dt); r = rng.integers(0, 1 << bd, (H, W)).astype(dt)
+        jb = stats.random_jobs(rng, W, H, 1200, subpel=True)
+        a = stats.run_oracle(oracle, s, r, jb, bd, satd=(bd == 8), psy_rd=1.0)
+        b = stats.run_hip(hip_ctx, s, r, jb, bd, satd=(bd == 8), psy_rd=1.0)
+        assert not mismatches(a, b, bd), bd
+
+
+def test_leaf_sub_pixel_variance(leaf, oracle):
+    rng = np.random.default_rng(33)
+    for (w, h) in [(4, 4), (8, 16), (16, 16), (64, 32), (128, 128)]:
+        for (xo, yo) in [(0, 0), (3, 0), (0, 5), (7, 7), (4, 4), (1, 6)]:
+            a = rng.integers(0, 256, (h + 1, w + 4)).astype(np.uint8); b = rng.integers(0, 256, (h, w + 2)).astype(np.uint8)
+            s1, s2 = C.c_uint32(), C.c_uint32()
+            x = getattr(leaf, f"svt_aom_sub_pixel_variance{w}x{h}_hip")(p(a), w + 4, xo, yo, p(b), w + 2, C.byref(s1)) & 0xFFFFFFFF
+            y = oracle.orc_sub_pixel_variance8(p(a), w + 4, xo, yo, p(b), w + 2, w, h, C.byref(s2)) & 0xFFFFFFFF
+            assert (x, s1.value) == (y, s2.value), (w, h, xo, yo)
