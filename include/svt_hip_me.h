@@ -51,6 +51,7 @@ typedef struct SvtHipMeConfig {
     SvtHipSearchAreaMinMax me_sa;
     /* PreHmeCtrls */
     uint8_t                prehme_enable, prehme_skip_search_line, prehme_l1_early_exit;
+    uint8_t                me_type; /* 0: ME_OPEN_LOOP and friends; 1: ME_MCTF (temporal filter, me_context.h:44-51) -- see svt_hip_me_picture */
     SvtHipSearchAreaMinMax prehme_sa_cfg[2];
     /* MeHmeRefPruneCtrls */
     uint8_t  enable_me_hme_ref_pruning;
@@ -122,6 +123,7 @@ typedef struct SvtHipMePictureDesc {
     /* first b64 row handled by this call and number of rows (row-band sharding across GPUs);
      * b64_row_count == 0 means "all rows". */
     uint16_t b64_row_start, b64_row_count;
+    uint32_t tf_me_exit_th; /* MeContext.tf_me_exit_th (me_context.h:495), read when cfg.me_type == 1 */
     uint64_t ref_picture_number[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS];
 } SvtHipMePictureDesc;
 

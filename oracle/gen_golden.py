@@ -32,14 +32,21 @@ ME_CASES = {
     "me_odd_m6_b": dict(width=360, height=296, enc_mode=6, seed=5),  # partial b64 columns/rows (40x40 edge blocks)
     "me_cif_m4_gm": dict(width=352, height=288, enc_mode=4, gm_enabled=1, kind="fastpan"),
     "me_cif_m10_sc": dict(width=352, height=288, enc_mode=10, sc_class1=1, kind="extremes"),
+    # temporal-filter ME (ME_MCTF): one reference, early exit on part of the blocks; search-level outputs only
+    "me_vga_m4_mctf": dict(width=640, height=360, enc_mode=4, refs={(0, 0): 1}, mctf_exit_th=6940, seed=3),
 }
 
 
-def gen_me():
+def gen_me(only=None):
+    from me_cases import MCTF_OUTPUTS
     for name, kw in ME_CASES.items():
+        if only and name not in only:
+            continue
         c = MeCase(**kw)
         out = c.run_cpu("ref")
         chk = c.run_cpu("oracle")
+        if "mctf_exit_th" in kw:
+            out = {k: out[k] for k in MCTF_OUTPUTS}
         for k in out:
             assert np.array_equal(out[k], chk[k]), (name, k)
         frames = {"cur": c.cur.inner(2)}
@@ -174,7 +181,7 @@ def gen_block_stats():
     print("wrote block_stats")
 
 
-GENERATORS = {"me": gen_me, "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats}
+GENERATORS = {"me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

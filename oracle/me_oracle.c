@@ -696,7 +696,8 @@ static void integer_search(MeState *s) {
             if (!s->sr[li][ri].do_ref)
                 continue;
             int16_t  cx = s->sr[li][ri].hme_sc_x, cy = s->sr[li][ri].hme_sc_y;
-            uint16_t dist = scaled_distance(ref_distance(s, li, ri)); /* me_type != ME_MCTF */
+            uint16_t dist = (uint16_t)ref_distance(s, li, ri);
+            if (c->me_type != 1) dist = scaled_distance(dist); /* me_type != ME_MCTF, :1299-1302 */
             int16_t  sa_w = (int16_t)ORC_MIN(c->me_sa.sa_min.width * dist, c->me_sa.sa_max.width);
             int16_t  sa_h = (int16_t)ORC_MIN(c->me_sa.sa_min.height * dist, c->me_sa.sa_max.height);
             if (c->mv_sa_adj_enabled && (!c->mv_sa_adj_nearest_ref_only || ri == 0)) {
@@ -973,7 +974,7 @@ static void gm_detection(MeState *s, const SbOut *o, uint8_t *stationary, uint8_
 }
 
 /* Whole-picture driver: the b64 loop of svt_aom_motion_estimation_kernel (Codec/me_process.c:174-290)
- * around svt_aom_motion_estimation_b64 (Codec/motion_estimation.c:3076-3153), ME_OPEN_LOOP only. */
+ * around svt_aom_motion_estimation_b64 (Codec/motion_estimation.c:3076-3153); cfg->me_type 1 = ME_MCTF. */
 int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, const SvtHipPlaneDesc cur_planes[3],
                    const SvtHipPlaneDesc ref_planes[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS][3], SvtHipMeResults *res) {
     OrcPyramid cur, refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS];
@@ -1032,11 +1033,19 @@ int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
                 if (cfg->enable_hme_level2_flag) hme_level12_b64(s, 2);
             }
             set_final_search_centre(s);
-            if (cfg->enable_hme_flag)
-                hme_prune_and_adjust(s);
-            integer_search(s);
-            if (cfg->enable_hme_flag && cfg->enable_me_hme_ref_pruning)
-                me_prune_ref(s);
+            const int mctf    = cfg->me_type == 1;
+            const int tf_exit = mctf && s->sr[0][0].hme_sad < desc->tf_me_exit_th; /* :3109-3113 */
+            if (!tf_exit) {
+                if (cfg->enable_hme_flag && !mctf) /* prune_ref, :3103,3115 */
+                    hme_prune_and_adjust(s);
+                integer_search(s);
+                if (cfg->enable_hme_flag && !mctf && cfg->enable_me_hme_ref_pruning)
+                    me_prune_ref(s);
+            } else /* the reference leaves p_sb_best_sad stale here; canonical value = never searched */
+                for (int li = 0; li < 2; li++)
+                    for (int ri = 0; ri < 4; ri++)
+                        for (int n = 0; n < 85; n++) s->best_sad[li][ri][n] = SVT_HIP_MAX_SAD_VALUE;
+            if (mctf) goto search_level_results; /* :3126 */
             SbOut o = {res->total_me_candidate_index + (size_t)b * n_pu, res->me_mv_array + (size_t)b * n_pu * desc->max_refs,
                        res->me_candidate_array + (size_t)b * n_pu * desc->max_cand};
             construct_candidates(s, &o);
@@ -1063,6 +1072,7 @@ int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
             res->rc_me_allow_gm[b]              = 0;
             if (desc->gm_enabled)
                 gm_detection(s, &o, &res->stationary_block_present_sb[b], &res->rc_me_allow_gm[b]);
+        search_level_results:
             /* optional search-level results, canonicalised for refs that were not searched */
             for (int li = 0; li < 2; li++)
                 for (int ri = 0; ri < 4; ri++) {

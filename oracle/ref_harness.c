@@ -261,7 +261,8 @@ int ref_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
         g->height                   = (uint8_t)((desc->aligned_height - g->org_y) < 64 ? desc->aligned_height - g->org_y : 64);
     }
     ctx_from_cfg(cfg, m);
-    m->me_type               = ME_OPEN_LOOP;
+    m->me_type               = cfg->me_type == 1 ? ME_MCTF : ME_OPEN_LOOP;
+    m->tf_me_exit_th         = (uint16_t)desc->tf_me_exit_th;
     m->num_of_list_to_search = desc->num_of_list_to_search;
     m->num_of_ref_pic_to_search[0] = desc->num_of_ref_pic_to_search[0];
     m->num_of_ref_pic_to_search[1] = desc->num_of_ref_pic_to_search[1];
@@ -301,9 +302,11 @@ int ref_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
                         res->hme_sc[2 * k + 1] = live ? m->search_results[li][ri].hme_sc_y : 0;
                     }
                     if (res->hme_sad) res->hme_sad[k] = live ? (uint32_t)m->search_results[li][ri].hme_sad : 0;
+                    /* ME_MCTF early exit (motion_estimation.c:3109-3113) leaves p_sb_best_sad of the previous block: canonical MAX */
+                    const int tf_exit = cfg->me_type == 1 && m->search_results[0][0].hme_sad < m->tf_me_exit_th;
                     for (int n = 0; n < 85; n++) {
                         const int ok = live && m->search_results[li][ri].do_ref;
-                        if (res->sb_best_sad) res->sb_best_sad[k * 85 + n] = ok ? m->p_sb_best_sad[li][ri][n] : MAX_SAD_VALUE;
+                        if (res->sb_best_sad) res->sb_best_sad[k * 85 + n] = (ok && !tf_exit) ? m->p_sb_best_sad[li][ri][n] : MAX_SAD_VALUE;
                         if (res->sb_best_mv) res->sb_best_mv[k * 85 + n] = ok ? m->p_sb_best_mv[li][ri][n] : 0;
                     }
                 }

@@ -27,7 +27,7 @@ class MeConfig(C.Structure):
         ("num_hme_sa_w", C.c_uint16), ("num_hme_sa_h", C.c_uint16),
         ("hme_l0_sa", SearchAreaMinMax), ("hme_l1_sa", SearchArea), ("hme_l2_sa", SearchArea),
         ("me_sa", SearchAreaMinMax),
-        ("prehme_enable", C.c_uint8), ("prehme_skip_search_line", C.c_uint8), ("prehme_l1_early_exit", C.c_uint8),
+        ("prehme_enable", C.c_uint8), ("prehme_skip_search_line", C.c_uint8), ("prehme_l1_early_exit", C.c_uint8), ("me_type", C.c_uint8),
         ("prehme_sa_cfg", SearchAreaMinMax * 2),
         ("enable_me_hme_ref_pruning", C.c_uint8),
         ("prune_ref_if_hme_sad_dev_bigger_than_th", C.c_uint16), ("prune_ref_if_me_sad_dev_bigger_than_th", C.c_uint16),
@@ -78,7 +78,7 @@ class MePictureDesc(C.Structure):
         ("similar_brightness_refs", C.c_uint8), ("enable_me_8x8", C.c_uint8), ("enable_me_16x16", C.c_uint8),
         ("max_number_of_pus_per_sb", C.c_uint8), ("max_cand", C.c_uint8), ("max_refs", C.c_uint8), ("max_l0", C.c_uint8),
         ("input_resolution", C.c_uint8), ("only_l_bwd", C.c_uint8), ("gm_enabled", C.c_uint8),
-        ("gm_use_distance_based_active_th", C.c_uint8), ("b64_row_start", C.c_uint16), ("b64_row_count", C.c_uint16),
+        ("gm_use_distance_based_active_th", C.c_uint8), ("b64_row_start", C.c_uint16), ("b64_row_count", C.c_uint16), ("tf_me_exit_th", C.c_uint32),
         ("ref_picture_number", (C.c_uint64 * MAX_REFS) * MAX_LISTS),
     ]
 

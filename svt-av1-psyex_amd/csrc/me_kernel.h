@@ -37,7 +37,7 @@ struct DevSearchAreaMinMax { DevSearchArea sa_min, sa_max; };
 
 #define SVT_ME_CFG_SMALL(X) X(hme_search_method) X(me_search_method) X(enable_hme_flag) X(enable_hme_level0_flag) \
     X(enable_hme_level1_flag) X(enable_hme_level2_flag) X(num_hme_sa_w) X(num_hme_sa_h) X(prehme_enable) \
-    X(prehme_skip_search_line) X(prehme_l1_early_exit) X(enable_me_hme_ref_pruning) \
+    X(prehme_skip_search_line) X(prehme_l1_early_exit) X(me_type) X(enable_me_hme_ref_pruning) \
     X(prune_ref_if_hme_sad_dev_bigger_than_th) X(prune_ref_if_me_sad_dev_bigger_than_th) X(zz_sad_pct) X(phme_sad_pct) \
     X(enable_me_sr_adjustment) X(reduce_me_sr_based_on_mv_length_th) X(stationary_hme_sad_abs_th) \
     X(stationary_me_sr_divisor) X(reduce_me_sr_based_on_hme_sad_abs_th) X(me_sr_divisor_for_low_hme_sad) \
@@ -69,6 +69,8 @@ struct DevMeDesc {
     SVT_ME_DESC_SMALL(SVT_X)
 #undef SVT_X
     int32_t num_of_ref_pic_to_search[SVT_HIP_MAX_LISTS];
+    uint32_t tf_me_exit_th;
+    uint32_t pad;
 };
 
 #ifdef __cplusplus
@@ -85,6 +87,8 @@ static inline void dev_me_config(DevMeConfig &o, const SvtHipMeConfig &c) {
 }
 static inline void dev_me_desc(DevMeDesc &o, const SvtHipMePictureDesc &d) {
     o.picture_number = d.picture_number;
+    o.tf_me_exit_th = d.tf_me_exit_th;
+    o.pad = 0;
     for (int l = 0; l < SVT_HIP_MAX_LISTS; l++) {
         o.num_of_ref_pic_to_search[l] = d.num_of_ref_pic_to_search[l];
         for (int r = 0; r < SVT_HIP_MAX_REFS; r++) o.ref_picture_number[l][r] = d.ref_picture_number[l][r];

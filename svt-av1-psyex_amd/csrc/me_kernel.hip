@@ -139,7 +139,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     uint32_t me_dist[85];
     uint8_t  cand0[88];  // candidate 0 of every PU (row order), for perform_gm_detection
     uint32_t red[8];
-    int      job;
+    int      job, tf_exit;
 };
 
 struct Shared {
@@ -809,6 +809,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         auto &d = p.desc;
         const int full_hme = (c.hme_search_method == 1);
         const int nl       = d.num_of_list_to_search;
+        const bool mctf    = c.me_type == 1; // ME_MCTF: no reference pruning, unscaled distance, HME-SAD early exit, search-level results only
         const int job      = gjob - (int)hdr.job_base[pic];
         const uint32_t bxi = (uint32_t)job % p.w64, byi = p.row0 + (uint32_t)job / p.w64;
         const uint32_t b   = bxi + byi * p.w64;
@@ -1126,7 +1127,9 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                             st.hme_sc_x[li][ri] = sx; st.hme_sc_y[li][ri] = sy; st.hme_sad64[li][ri] = hme_sad;
                         }
                 }
-                if (c.enable_hme_flag) {
+                // ME_MCTF leaves after HME when list0/ref0 already matches (motion_estimation.c:3109-3113)
+                st.tf_exit = mctf && st.hme_sad64[0][0] < (u64)d.tf_me_exit_th;
+                if (c.enable_hme_flag && !mctf) { // hme_prune_ref_and_adjust_sr is skipped for ME_MCTF (:3103,3115)
                     const uint16_t th = c.prune_ref_if_hme_sad_dev_bigger_than_th;
                     if (c.enable_me_hme_ref_pruning && th != 0xFFFF) {
                         u64 best = ~0ull;
@@ -1186,7 +1189,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                         if (!st.do_ref[li][ri]) continue;
                         CPlane &rp = p.ref[li][ri].lvl[2];
                         int16_t  cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
-                        const uint32_t dist = (uint16_t)scaled_distance(ref_distance(p, li, ri));
+                        const uint32_t dist = mctf ? (uint16_t)ref_distance(p, li, ri) : (uint16_t)scaled_distance(ref_distance(p, li, ri)); // :1299-1302
                         int16_t sa_w = (int16_t)imin((int)(c.me_sa.sa_min.width * dist), c.me_sa.sa_max.width);
                         int16_t sa_h = (int16_t)imin((int)(c.me_sa.sa_min.height * dist), c.me_sa.sa_max.height);
                         if (c.mv_sa_adj_enabled && (!c.mv_sa_adj_nearest_ref_only || ri == 0)) {
@@ -1267,6 +1270,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             if (run) {
                 __syncthreads();
                 PROF(step == kMain ? 20 : 6 + step);
+                if (step == kC00 && bi == 0 && st.tf_exit) { step = kEnd; continue; } // uniform: LDS value read after the barrier
                 if (step < kProbe) {
                     if (st.nreq) run_searches(sh PROF_ARG); // uniform (LDS value read after the barrier)
                 } else {
@@ -1304,7 +1308,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
 
 
         // ---- me_prune_ref (motion_estimation.c:1522-1565) ----------------------------------------------------
-        if (c.enable_hme_flag && c.enable_me_hme_ref_pruning) {
+        if (c.enable_hme_flag && c.enable_me_hme_ref_pruning && !mctf) {
             for (int r = tid >> 6; r < 8; r += kWaves) { // one wave per reference: sum of its 64 8x8 SADs
                 const int li = r >> 2, ri = r & 3;
                 if (li >= nl || ri >= d.num_of_ref_pic_to_search[li]) continue;
@@ -1326,7 +1330,9 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
 
         PROF(13);
         // ---- construct_me_candidate_array* (motion_estimation.c:2532-2836), one thread per PU ----------------
+        // (not for ME_MCTF, :3126: the temporal filter consumes p_sb_best_sad / p_sb_best_mv)
         {
+          if (!mctf) {
             const uint32_t n_pu = p.n_pu;
             uint8_t  *o_total = p.res.total_me_candidate_index + (size_t)b * n_pu;
             uint32_t *o_mv    = p.res.me_mv_array + (size_t)b * n_pu * d.max_refs;
@@ -1487,6 +1493,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 p.res.rc_me_allow_gm[b]              = allow_gm;
               }
             }
+          }
             PROF(15);
             // ---- optional search-level results ------------------------------------------------------------------
             if (p.res.sb_best_sad || p.res.sb_best_mv)

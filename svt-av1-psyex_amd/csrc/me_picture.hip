@@ -4,6 +4,12 @@
 #include <string.h>
 #include "svt_hip_internal.h"
 
+#include <stddef.h>
+// the two MCTF fields sit in what used to be padding: the layout of both descriptors (and every stored fixture) is unchanged
+static_assert(offsetof(SvtHipMeConfig, me_type) == 37 && offsetof(SvtHipMeConfig, prehme_sa_cfg) == 38 && sizeof(SvtHipMeConfig) == 128, "SvtHipMeConfig layout");
+static_assert(offsetof(SvtHipMePictureDesc, tf_me_exit_th) == 36 && offsetof(SvtHipMePictureDesc, ref_picture_number) == 40 && sizeof(SvtHipMePictureDesc) == 104,
+              "SvtHipMePictureDesc layout");
+
 namespace {
 
 struct Geometry {
@@ -16,6 +22,10 @@ int validate(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictur
     if (cfg->num_hme_sa_w != 2 || cfg->num_hme_sa_h != 2)
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "num_hme_sa_w/h must be 2x2 (got %ux%u)", cfg->num_hme_sa_w, cfg->num_hme_sa_h);
     if (cfg->hme_search_method > 1 || cfg->me_search_method > 1) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "search method must be 0 or 1");
+    if (cfg->me_type > 1) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "me_type %u (0 = open loop, 1 = ME_MCTF)", cfg->me_type);
+    if (cfg->me_type == 1 && d->tf_me_exit_th > 0xFFFF) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tf_me_exit_th %u does not fit the reference's uint16", d->tf_me_exit_th);
+    if (cfg->me_type == 1 && (!res->sb_best_sad || !res->sb_best_mv || !res->hme_sad || !res->hme_sc))
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "ME_MCTF returns its results through sb_best_sad / sb_best_mv / hme_sad / hme_sc");
     const uint16_t lim = 2048; // keeps every int16 search-area product of the reference in range
     if (cfg->me_sa.sa_max.width > lim || cfg->me_sa.sa_max.height > lim || cfg->hme_l0_sa.sa_max.width > lim ||
         cfg->hme_l0_sa.sa_max.height > lim || cfg->prehme_sa_cfg[0].sa_max.height > lim || cfg->prehme_sa_cfg[1].sa_max.width > lim ||

@@ -40,7 +40,7 @@ class MeCase:
 
     def __init__(self, width, height, enc_mode=6, cur=2, refs=None, seed=1234, kind="pan", temporal_layer_index=1,
                  hierarchical_levels=4, is_ref=1, gm_enabled=0, qp=35, sc_class1=0, rtc_tune=0, n_frames=None, cfg_edit=None,
-                 pad=68):
+                 pad=68, mctf_exit_th=None):
         refs = refs if refs is not None else {(0, 0): 0, (1, 0): 3}
         n_frames = n_frames or (max([cur] + list(refs.values())) + 1)
         frames = sequence(width, height, n_frames, seed, kind)
@@ -53,6 +53,9 @@ class MeCase:
             cfg_edit(self.cfg)
         self.desc = api.picture_desc(width, height, cur, refs, enc_mode=enc_mode, temporal_layer_index=temporal_layer_index,
                                      hierarchical_levels=hierarchical_levels, is_ref=is_ref, gm_enabled=gm_enabled, rtc_tune=rtc_tune)
+        if mctf_exit_th is not None:  # temporal-filter ME (ME_MCTF): search-level results only
+            self.cfg.me_type = 1
+            self.desc.tf_me_exit_th = mctf_exit_th
 
     def run_cpu(self, which="oracle"):
         import pyoracle
@@ -77,3 +80,14 @@ def compare(a, b, names=None):
             idx = np.argwhere(a[k] != b[k])
             bad.append(f"{k}: {len(idx)} mismatches, first at {tuple(idx[0])}: {a[k][tuple(idx[0])]} vs {b[k][tuple(idx[0])]}")
     return bad
+
+
+MCTF_OUTPUTS = ("sb_best_sad", "sb_best_mv", "hme_sc", "hme_sad", "do_ref")  # what ME_MCTF produces (motion_estimation.c:3126)
+
+MCTF_GRID = [
+    dict(width=352, height=288, enc_mode=6, refs={(0, 0): 1}, mctf_exit_th=0),                      # no early exit
+    dict(width=352, height=288, enc_mode=6, refs={(0, 0): 0}, mctf_exit_th=40000, seed=2),          # every block exits
+    dict(width=640, height=360, enc_mode=4, refs={(0, 0): 1}, mctf_exit_th=6940, seed=3),           # mixed
+    dict(width=352, height=288, enc_mode=9, refs={(0, 0): 1, (1, 0): 3}, mctf_exit_th=25000, kind="fastpan"),
+    dict(width=352, height=288, enc_mode=2, cur=2, refs={(0, 0): 1, (0, 1): 0, (1, 0): 3, (1, 1): 4}, n_frames=5, mctf_exit_th=100),
+]

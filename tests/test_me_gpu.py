@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from golden_io import GoldenMeCase, me_fixture_names
-from me_cases import MeCase, compare
+from me_cases import MCTF_GRID, MCTF_OUTPUTS, MeCase, compare
 from test_oracle_vs_ref import ME_GRID
 
 pytestmark = pytest.mark.gpu
@@ -184,3 +184,9 @@ def api_rc_too_many(ctx, job):
     from svt_av1_psyex_amd import abi, api
     arr = (abi.MeJob * 17)()
     return api.lib().svt_hip_me_pictures_async(ctx._h, 17, arr)
+
+
+@pytest.mark.parametrize("kw", MCTF_GRID, ids=lambda k: f"{k['width']}x{k['height']}_m{k['enc_mode']}_th{k['mctf_exit_th']}")
+def test_mctf_matches_oracle(hip_ctx, kw):
+    case = MeCase(**kw)
+    assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx), MCTF_OUTPUTS)

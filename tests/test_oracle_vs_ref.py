@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from me_cases import MeCase, compare
+from me_cases import MCTF_GRID, MCTF_OUTPUTS, MeCase, compare
 
 P = C.c_void_p
 
@@ -94,6 +94,17 @@ ME_GRID = [
 def test_me_picture_oracle_equals_reference(ref, kw):
     case = MeCase(**kw)
     assert not compare(case.run_cpu("ref"), case.run_cpu("oracle"))
+
+
+@pytest.mark.parametrize("kw", MCTF_GRID, ids=lambda k: f"{k['width']}x{k['height']}_m{k['enc_mode']}_th{k['mctf_exit_th']}")
+def test_mctf_oracle_equals_reference(ref, kw):
+    """me_type == ME_MCTF (motion_estimation.c:1299-1302,3103-3126): unscaled distance, no pruning, HME-SAD early exit."""
+    case = MeCase(**kw)
+    a, b = case.run_cpu("ref"), case.run_cpu("oracle")
+    assert not compare(a, b, MCTF_OUTPUTS)
+    exits = (a["hme_sad"].reshape(-1, 8)[:, 0] < kw["mctf_exit_th"]).mean()
+    if kw["mctf_exit_th"] == 6940:
+        assert 0.02 < exits < 0.98, exits  # the mixed case really mixes
 
 
 def test_full_sad_search_method(ref):
