@@ -505,7 +505,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(con
         int32_t x[H];
         const int ic = lr ? W - 1 - l : l;
 #pragma unroll
-        for (int r = 0; r < H; r++) x[r] = clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16);
+        for (int r = 0; r < H; r++) x[r] = (r < HP) ? clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16) : 0; // rows >= 32 of a 64-row block are exactly zero after the row pass: constants, so the network prunes itself
         inv_1d<H, COL_CLAMP>(x, vt);
         shift_vec<H>(x, -4);
         Pix *rec = (p.d.recon && valid) ? static_cast<Pix *>(p.d.recon) + jb.pred_offset : nullptr;

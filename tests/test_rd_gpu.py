@@ -91,3 +91,18 @@ def test_partial_frequency_shapes_and_quantization_matrices(hip_ctx, tx_size):
                 want = rd.run_oracle(f, src, pred, jobs, rows, qmatrix=qm, iqmatrix=iqm)
                 got = rd.run_hip(hip_ctx, f, src, pred, jobs, rows, qmatrix=qm, iqmatrix=iqm)
                 _check(want, got, (tx_size, bd, quant_kind, use_qm))
+
+
+@pytest.mark.parametrize("tx_size", [1, 3, 4, 10, 17])
+def test_out_of_range_16bit_samples_stay_exact(hip_ctx, tx_size):
+    """uint16 planes holding values beyond 10 bits: the forward transform's 24-bit-multiply fast path must not be taken
+    (residuals up to +-32767 overflow 24 bits inside the 64-point passes); results still equal the oracle's wrapping arithmetic."""
+    rng = np.random.default_rng(900 + tx_size)
+    rows = np.stack([rd.quant_row_from_step(60, 75)])
+    src = rng.integers(0, 65536, (128, 192)).astype(np.uint16)
+    pred = rng.integers(0, 65536, (128, 192)).astype(np.uint16)
+    src[:64] = np.clip(src[:64], 0, 1023); pred[:64] = np.clip(pred[:64], 0, 1023)  # valid and invalid blocks in one batch
+    jobs = rd.grid_jobs(192, 128, 192, tx_size)
+    jobs["tx_type"] = rng.choice(valid_types(tx_size), len(jobs))
+    f = dict(bit_depth=10, quant_kind=0, tx_size=tx_size, src_stride=192, pred_stride=192)
+    _check(rd.run_oracle(f, src, pred, jobs, rows), rd.run_hip(hip_ctx, f, src, pred, jobs, rows), tx_size)
