@@ -353,7 +353,18 @@ __host__ __device__ constexpr int rd_blocks_per_wave(int ts) { return 64 / rd_la
 // (top-left 32x32) coefficients of the 64-point sizes are compacted in place as well, which is what lets nine
 // 64x64 workgroups share a CU's LDS.
 // =========================================================================================================
-template <int TS, int BD> __global__ void __launch_bounds__(64) rd_tx_kernel(const RdParams p) {
+// resident waves per SIMD the register allocation aims for: enough workgroups in flight that a picture's blocks of one size
+// run as a single round (e.g. 32x32: 4,020 two-block workgroups on 256 CUs x 4 SIMDs x 4 waves)
+#ifndef SVT_RD_WAVES_32
+#define SVT_RD_WAVES_32 4
+#endif
+#ifndef SVT_RD_WAVES_16
+#define SVT_RD_WAVES_16 4
+#endif
+__host__ __device__ constexpr int rd_waves_per_simd(int ts) {
+    return rd_lanes_per_block(ts) == 64 ? 2 : rd_lanes_per_block(ts) == 32 ? SVT_RD_WAVES_32 : SVT_RD_WAVES_16;
+}
+template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_simd(TS)) rd_tx_kernel(const RdParams p) {
     constexpr int W = tx_wide(TS), H = tx_high(TS), WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
     constexpr int LW = rd_lanes_per_block(TS), BPW = rd_blocks_per_wave(TS);
     constexpr int PA = W + 1, PB = WP + 1; // row pitches (dwords) of the full block and of the packed coefficients
