@@ -4,16 +4,17 @@
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
-A *step* = one mini-GOP slice of 4 pictures of the sequence (reference distances 1, 2, 4, 8; temporal layers 4..1;
-R = 2 references per picture, one per list), each going through
-  1. open-loop ME for every 64x64 block (== N x svt_aom_motion_estimation_b64); the four pictures of the step are in
+A *step* = one mini-GOP worth of 16 pictures of the sequence (4 current pictures x reference distances 1, 2, 4, 8;
+temporal layers 4..1; R = 2 references per picture, one per list), each going through
+  1. open-loop ME for every 64x64 block (== N x svt_aom_motion_estimation_b64); the pictures of the step are in
      flight together, as in the reference's ME threads, and share ONE launch (svt_hip_me_pictures_async),
   2. full-pel motion-compensated 10-bit prediction from the ME winners (svt_hip_fullpel_pred, one launch per picture),
   3. the RD kernels on the 10-bit luma at three transform depths (64x64, 32x32, 16x16, DCT_DCT, "b" quantizer):
      residual -> fwd txfm -> SATD -> quantize -> coeff distortion -> inv txfm -> SSE (svt_hip_rd_batch; one batch per
-     depth holds the blocks of all four pictures).
+     depth holds the blocks of all pictures of the step).
 With N GPUs the b64 rows of every picture are sharded across the ranks (all planes are replicated; no halo
-exchange) and the per-b64 ME results are all-gathered over RCCL once per step -- the exchange north_star names.
+exchange) and the per-b64 ME results (MeSbResults arrays + the per-b64 scalars, ~1 KB per block) are all-gathered over
+RCCL once per step, on a side stream behind the ME launch so that it overlaps the prediction / RD kernels.
 `value` = luma pixels of the pictures fully processed per second, whole job (strong scaling: the pictures per step
 are fixed, each rank handles 1/N of the b64 rows).
 """
@@ -36,8 +37,10 @@ from svt_av1_psyex_amd import abi, api, rd, shard, synth  # noqa: E402
 W, H = 3840, 2160
 DISTS = (1, 2, 4, 8)
 LAYER = {1: 4, 2: 3, 4: 2, 8: 1}
-CUR = 8
-N_FRAMES = 17
+CURS = (8, 9, 10, 11)  # current pictures of one step; picture p = (CURS[p // 4], DISTS[p % 4])
+CUR = CURS[0]
+PICS = [(cur, d) for cur in CURS for d in DISTS]
+N_FRAMES = max(CURS) + max(DISTS) + 1
 RD_SIZES = (4, 3, 2)  # TX_64X64, TX_32X32, TX_16X16
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
@@ -57,27 +60,33 @@ class Workload:
         self.host8 = {i: synth.HostPyramid(y8[i], i) for i in range(N_FRAMES)}
         self.y10_host = y10
         self.pics = {i: ctx.upload(self.host8[i]) for i in range(N_FRAMES)}
-        self.y10 = {i: torch.from_numpy(y10[i].astype(np.int16)).cuda().view(torch.int16) for i in (CUR,) + tuple(CUR - d for d in DISTS)}
+        # 10-bit planes: the current pictures contiguous (one RD batch addresses all of them), the references one by one
+        self.src10 = torch.from_numpy(np.stack([y10[c] for c in CURS]).astype(np.int16)).cuda().view(torch.int16).reshape(-1)
+        self.y10 = {i: torch.from_numpy(y10[i].astype(np.int16)).cuda().view(torch.int16) for i in sorted({c - d for c, d in PICS})}
         self.w64, self.h64 = (W + 63) // 64, (H + 63) // 64
         self.row0, self.row1 = shard.band(self.h64, rank, world)  # contiguous b64 row band of this rank
         self.cfgs, self.descs = {}, {}
-        for d in DISTS:
-            self.cfgs[d] = api.config_from_preset(6, W, H, qp=35, temporal_layer_index=LAYER[d], hierarchical_levels=4)
-            desc = api.picture_desc(W, H, CUR, {(0, 0): CUR - d, (1, 0): CUR + d}, enc_mode=6, temporal_layer_index=LAYER[d], hierarchical_levels=4)
+        for cur, d in PICS:
+            self.cfgs[(cur, d)] = api.config_from_preset(6, W, H, qp=35, temporal_layer_index=LAYER[d], hierarchical_levels=4)
+            desc = api.picture_desc(W, H, cur, {(0, 0): cur - d, (1, 0): cur + d}, enc_mode=6, temporal_layer_index=LAYER[d], hierarchical_levels=4)
             desc.b64_row_start, desc.b64_row_count = self.row0, self.row1 - self.row0
-            self.descs[d] = desc
+            self.descs[(cur, d)] = desc
         self.n_pu = abi.n_pu(desc.enable_me_16x16, desc.enable_me_8x8)
-        # ME results of the 4 pictures of a step: ONE compact device buffer holding only this rank's b64 rows (padded to
-        # the largest band so that every rank contributes the same byte count to the all-gather): shard.BandLayout.
-        self.layout = shard.BandLayout(self.w64, self.h64, world, self.n_pu, desc.max_refs, desc.max_cand, n_pictures=len(DISTS))
+        # ME results of the pictures of a step: ONE compact device buffer holding only this rank's b64 rows (padded to the
+        # largest band so that every rank contributes the same byte count to the all-gather): shard.BandLayout.  The
+        # search-level MVs that feed this rank's prediction stay in a local buffer.
+        self.layout = shard.BandLayout(self.w64, self.h64, world, self.n_pu, desc.max_refs, desc.max_cand, n_pictures=len(PICS))
         self.me_buf = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device="cuda")
+        nb = self.w64 * self.h64
+        self.mv_buf = torch.zeros(len(PICS) * nb * 680, dtype=torch.int32, device="cuda")
         self.me_res, self.mv_ptr = {}, {}
-        for pi, d in enumerate(DISTS):
-            self.me_res[d] = self.layout.results_struct(self.me_buf.data_ptr(), pi, rank)
-            self.mv_ptr[d] = self.me_res[d].sb_best_mv
+        for pi, pic in enumerate(PICS):
+            self.me_res[pic] = self.layout.results_struct(self.me_buf.data_ptr(), pi, rank)
+            self.mv_ptr[pic] = self.mv_buf.data_ptr() + pi * nb * 680 * 4
+            self.me_res[pic].sb_best_mv = self.mv_ptr[pic]
         # RD: one prediction / recon plane per picture of the step (contiguous, so that one batch addresses all of them) and
         # job lists restricted to this rank's rows
-        NP = len(DISTS)
+        NP = len(PICS)
         self.pred = torch.zeros(NP * H * W, dtype=torch.int16, device="cuda")
         self.recon = torch.zeros(NP * H * W, dtype=torch.int16, device="cuda")
         self.rows = torch.from_numpy(np.stack([rd.quant_row_from_step(140, 176)]).view(np.uint8).reshape(-1)).cuda()
@@ -92,27 +101,30 @@ class Workload:
             allp = []
             for pi in range(NP):
                 j = one.copy()
-                j["pred_offset"] += pi * H * W  # picture pi's prediction / recon plane; the source picture is shared
+                j["src_offset"] += (pi // len(DISTS)) * H * W  # its current picture
+                j["pred_offset"] += pi * H * W                 # its prediction / recon plane
                 allp.append(j)
             jobs = np.concatenate(allp)
             n = len(jobs)
             t_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).cuda()
             outs = {name: torch.zeros(max(n, 1) * k * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt, k in abi.RD_OUT_FIELDS}
-            d = abi.RdBatchDesc(bit_depth=10, quant_kind=0, tx_size=ts, n_jobs=n, src_stride=W, pred_stride=W, src=self.y10[CUR].data_ptr(),
+            d = abi.RdBatchDesc(bit_depth=10, quant_kind=0, tx_size=ts, n_jobs=n, src_stride=W, pred_stride=W, src=self.src10.data_ptr(),
                                 pred=self.pred.data_ptr(), recon=self.recon.data_ptr(), jobs=t_jobs.data_ptr(), quant_rows=self.rows.data_ptr(), n_quant_rows=1)
             for name, t in outs.items():
                 setattr(d, name, t.data_ptr())
             self.rd.append((ts, d, t_jobs, outs, n))
             self.rd_pixels += n * abi.TX_W[ts] * abi.TX_H[ts]  # per step (all pictures)
-        self.me_jobs = [(self.cfgs[d], self.descs[d], self.pics[CUR], self.refs(d), self.me_res[d]) for d in DISTS]
+        self.me_jobs = [(self.cfgs[pic], self.descs[pic], self.pics[pic[0]], self.refs(pic), self.me_res[pic]) for pic in PICS]
         torch.cuda.synchronize()
         log(f"[rank {rank}] setup {time.time() - t0:.1f}s: rows {self.row0}..{self.row1} of {self.h64}, RD jobs {[r[4] for r in self.rd]}")
 
-    def refs(self, d):
-        return {(0, 0): self.pics[CUR - d], (1, 0): self.pics[CUR + d]}
+    def refs(self, pic):
+        cur, d = pic
+        return {(0, 0): self.pics[cur - d], (1, 0): self.pics[cur + d]}
 
-    def step(self, ev=None):
-        """Enqueue one step on the context stream.  `ev`: optional dict collecting (start, end) event pairs per kernel family."""
+    def step(self, ev=None, after_me=None):
+        """Enqueue one step on the context stream.  `ev`: optional dict collecting (start, end) event pairs per kernel family;
+        `after_me`: callback run right behind the ME launch (the multi-GPU exchange hooks in there)."""
         L = api.lib()
         mark = lambda: None
         if ev is not None:
@@ -121,8 +133,10 @@ class Workload:
         e0 = mark()
         self.ctx.me_pictures_async(self.me_jobs)
         e1 = mark()
-        for pi, d in enumerate(DISTS):
-            self.ctx.check(L.svt_hip_fullpel_pred(self.ctx._h, C.c_void_p(self.y10[CUR - d].data_ptr()), W, W, H, 10, C.c_void_p(self.mv_ptr[d]), 0, 0,
+        if after_me is not None:
+            after_me()
+        for pi, (cur, d) in enumerate(PICS):
+            self.ctx.check(L.svt_hip_fullpel_pred(self.ctx._h, C.c_void_p(self.y10[cur - d].data_ptr()), W, W, H, 10, C.c_void_p(self.mv_ptr[(cur, d)]), 0, 0,
                                                   self.row0, self.row1 - self.row0, C.c_void_p(self.pred.data_ptr() + 2 * pi * H * W), W), "svt_hip_fullpel_pred")
         e2 = mark()
         for ts, desc, _, _, n in self.rd:
@@ -143,13 +157,13 @@ def cpu_baseline(wl, seconds_target=12.0):
     rows_total = cores  # one b64 row per thread
     row_start = wl.h64 // 2 - rows_total // 2
     d = 2
-    cfg = wl.cfgs[d]
+    cfg = wl.cfgs[(CUR, d)]
     src10 = wl.y10_host[CUR]
     pred10 = wl.y10_host[CUR - d]
     qrows = np.stack([rd.quant_row_from_step(140, 176)])
 
     def work(row):
-        desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[d]))
+        desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[(CUR, d)]))
         desc.b64_row_start, desc.b64_row_count = row, 1
         pyoracle.me_picture("oracle", cfg, desc, wl.host8[CUR], {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}, search_level=False)
         for ts in RD_SIZES:
@@ -179,7 +193,7 @@ def cpu_baseline(wl, seconds_target=12.0):
                 ref.ref_set_simd(1)
 
                 def work_ref(row):
-                    desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[d]))
+                    desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[(CUR, d)]))
                     desc.b64_row_start, desc.b64_row_count = row, 1
                     pyoracle.me_picture("ref", cfg, desc, wl.host8[CUR], {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}, search_level=False)
                 t1 = time.time()
@@ -195,7 +209,7 @@ def cpu_baseline(wl, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -220,13 +234,25 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
+    comm = torch.cuda.Stream() if world > 1 else None
+
+    def exchange():
+        # per-b64 best-cost / MV / candidate results of this rank's rows -> every rank (RCCL over xGMI), on a side stream
+        # ordered behind the ME launch; the prediction / RD kernels of the step overlap it
+        done = torch.cuda.Event()
+        done.record(ext)
+        with torch.cuda.stream(comm):
+            comm.wait_event(done)
+            dist.all_gather_into_tensor(gather_out, wl.me_buf)
+
     def run(steps, ev=None):
         with torch.cuda.stream(ext):
             for _ in range(steps):
-                wl.step(ev)
                 if world > 1:
-                    # per-b64 best-cost / MV / candidate results of this rank's rows -> every rank (RCCL over xGMI)
-                    dist.all_gather_into_tensor(gather_out, wl.me_buf)
+                    ext.wait_stream(comm)  # the previous exchange has read the result buffer this step's ME overwrites
+                wl.step(ev, exchange if world > 1 else None)
+        if world > 1:
+            ext.wait_stream(comm)          # the timed region ends when the last exchange has landed
 
     run(a.warmup)
     barrier()
@@ -243,12 +269,12 @@ def main():
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt = float(t_all.item())
-    pictures = a.steps * len(DISTS)
+    pictures = a.steps * len(PICS)
     value = pictures * W * H / dt / 1e6
     if rank == 0:
         R = 2
         frac_rows = (wl.row1 - wl.row0) / wl.h64
-        me_bytes = (1.3125 * (1 + R) + 0.166 * R) * W * H * frac_rows * len(DISTS)  # B_ME bytes per pixel x the 4 pictures of one launch
+        me_bytes = (1.3125 * (1 + R) + 0.166 * R) * W * H * frac_rows * len(PICS)  # B_ME bytes per pixel x the pictures of one launch
         rd_bytes = wl.rd_pixels * (2 * 2 + 4 + 2)  # B_RD = 2*bpp + 4 (+bpp recon), bpp = 2; the step's three launches
         dom = "me" if kms["me"] >= kms["rd"] / len(RD_SIZES) else "rd"  # the single kernel with the longest launch
         # HBM bytes per launch from the PMC passes committed under profiles/ (same command, N = 1): rocprofv3 cannot run
@@ -262,9 +288,9 @@ def main():
             "metric": "ME+RD-cost Mpixels/s (2160p10 preset-6)", "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8 SAD / i32 transforms", "data": "synthetic",
-            "config": {"workload": "3840x2160 10-bit synthetic pan sequence, preset 6 (M6) search controls at qp 35; step = 4 pictures (ref distance 1,2,4,8; R=2): "
+            "config": {"workload": "3840x2160 10-bit synthetic pan sequence, preset 6 (M6) search controls at qp 35; step = 16 pictures (4 current pictures x ref distance 1,2,4,8; R=2): "
                                    "open-loop ME of all 2040 b64 + full-pel pred + RD chain (64x64,32x32,16x16 DCT_DCT, 10-bit, b quantizer)",
-                       "pictures_per_step": len(DISTS), "b64_rows_per_rank": wl.row1 - wl.row0, "parallelism": f"b64-row bands x{world} + all-gather of ME results"},
+                       "pictures_per_step": len(PICS), "b64_rows_per_rank": wl.row1 - wl.row0, "parallelism": f"b64-row bands x{world} + all-gather of ME results"},
             "roofline": {"bound": "hbm", "kernel": "svt_hip_me_b64_kernel" if dom == "me" else "rd_tx_kernel (3 sizes)", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(me_bytes if dom == "me" else rd_bytes), "avg_launch_ms": round(kms[dom], 4)},

@@ -9,7 +9,9 @@ import numpy as np
 
 from . import abi
 
-GATHER_FIELDS = tuple(n for n, _, _ in abi.RESULT_FIELDS if n not in ("hme_sc", "hme_sad", "do_ref"))
+# what the host's entropy coder / MD consumes: the MeSbResults arrays and the per-b64 scalars (~1 KB per b64).  The
+# search-level arrays (p_sb_best_sad / mv, 5.4 KB per b64, mostly padding for unused reference slots) stay on the rank.
+GATHER_FIELDS = tuple(n for n, _, _ in abi.RESULT_FIELDS if n not in ("hme_sc", "hme_sad", "do_ref", "sb_best_sad", "sb_best_mv"))
 
 
 def band(h64, rank, world):
