@@ -629,22 +629,37 @@ int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d) {
 // of prediction this path needs to feed the RD kernels; sub-pel interpolation is out of scope.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-template <typename Pix> __global__ void fullpel_pred_kernel(const Pix *ref, uint32_t ref_stride, int width, int height, const uint32_t *sb_best_mv,
-                                                            int list, int ref_idx, uint32_t w64, int by16_first, Pix *pred, uint32_t pred_stride) {
-    const int bx16 = blockIdx.x, by16 = by16_first + (int)blockIdx.y; // 16x16 block coordinates
-    const int x0 = bx16 * 16, y0 = by16 * 16;
-    const uint32_t b = (uint32_t)(x0 >> 6) + (uint32_t)(y0 >> 6) * w64;
-    const int qx = (x0 >> 4) & 3, qy = (y0 >> 4) & 3;
-    const int z16 = (qx & 1) | ((qy & 1) << 1) | ((qx >> 1) << 2) | ((qy >> 1) << 3);
-    const uint32_t mv = sb_best_mv[((size_t)b * 8 + list * 4 + ref_idx) * 85 + 5 + z16];
-    const int mvx = (int16_t)(mv & 0xFFFF), mvy = (int16_t)(mv >> 16);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= width || y >= height) return;
-    int sx = x + mvx, sy = y + mvy;
-    sx = sx < 0 ? 0 : (sx > width - 1 ? width - 1 : sx);
-    sy = sy < 0 ? 0 : (sy > height - 1 ? height - 1 : sy);
-    pred[(size_t)y * pred_stride + x] = ref[(size_t)sy * ref_stride + sx];
+// one workgroup per 64x64 block; a thread copies runs of 8 samples (one 8- or 16-byte store; the source run starts at an
+// arbitrary sample, so its load is unaligned) and falls back to per-sample clamping where the run touches a picture edge
+template <typename Pix> __global__ void __launch_bounds__(256) fullpel_pred_kernel(const Pix *ref, uint32_t ref_stride, int width, int height,
+                                                                                   const uint32_t *sb_best_mv, int list, int ref_idx, uint32_t w64, int by64_first,
+                                                                                   Pix *pred, uint32_t pred_stride, int vec_ok) {
+    typedef Pix __attribute__((ext_vector_type(8), aligned(sizeof(Pix)))) RunU; // unaligned run of 8 samples
+    typedef Pix __attribute__((ext_vector_type(8))) Run;
+    const int bx = blockIdx.x, by = by64_first + (int)blockIdx.y;
+    const uint32_t b = (uint32_t)bx + (uint32_t)by * w64;
+    const uint32_t *mvs = sb_best_mv + ((size_t)b * 8 + list * 4 + ref_idx) * 85 + 5; // the 16 16x16 PUs, quad-tree order
+    for (int seg = threadIdx.x; seg < 64 * 8; seg += 256) {
+        const int ly = seg >> 3, lx = (seg & 7) * 8, x = bx * 64 + lx, y = by * 64 + ly;
+        if (x >= width || y >= height) continue;
+        const int qx = lx >> 4, qy = ly >> 4;
+        const uint32_t mv = mvs[(qx & 1) | ((qy & 1) << 1) | ((qx >> 1) << 2) | ((qy >> 1) << 3)];
+        const int mvx = (int16_t)(mv & 0xFFFF), mvy = (int16_t)(mv >> 16);
+        int sy = y + mvy;
+        sy = sy < 0 ? 0 : (sy > height - 1 ? height - 1 : sy);
+        const int sx = x + mvx;
+        const Pix *srow = ref + (size_t)sy * ref_stride;
+        Pix       *drow = pred + (size_t)y * pred_stride + x;
+        if (vec_ok && sx >= 0 && sx + 8 <= width && x + 8 <= width) {
+            *reinterpret_cast<Run *>(drow) = *reinterpret_cast<const RunU *>(srow + sx);
+        } else {
+            for (int i = 0; i < 8 && x + i < width; i++) {
+                int cx = sx + i;
+                cx = cx < 0 ? 0 : (cx > width - 1 ? width - 1 : cx);
+                drow[i] = srow[cx];
+            }
+        }
+    }
 }
 } // namespace
 
@@ -657,14 +672,15 @@ extern "C" int svt_hip_fullpel_pred(SvtHipContext *ctx, const void *ref, uint32_
     const uint32_t w64 = (width + 63) / 64, h64 = (height + 63) / 64;
     if (b64_row_start >= h64) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "svt_hip_fullpel_pred: b64_row_start %u >= %u", b64_row_start, h64);
     if (b64_row_count == 0 || b64_row_start + b64_row_count > h64) b64_row_count = h64 - b64_row_start;
-    const uint32_t y_lo = b64_row_start * 64, y_hi = (b64_row_start + b64_row_count) * 64 < height ? (b64_row_start + b64_row_count) * 64 : height;
-    const dim3 g((width + 15) / 16, (y_hi - y_lo + 15) / 16), blk(256);
+    const dim3 g(w64, b64_row_count), blk(256);
+    const size_t bpp = bit_depth == 8 ? 1 : 2;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(pred) % (8 * bpp)) == 0 && pred_stride % 8 == 0) ? 1 : 0; // aligned 8-sample stores
     if (bit_depth == 8)
         hipLaunchKernelGGL(fullpel_pred_kernel<uint8_t>, g, blk, 0, ctx->stream, static_cast<const uint8_t *>(ref), ref_stride, (int)width, (int)height,
-                           sb_best_mv, (int)list, (int)ref_idx, w64, (int)(y_lo / 16), static_cast<uint8_t *>(pred), pred_stride);
+                           sb_best_mv, (int)list, (int)ref_idx, w64, (int)b64_row_start, static_cast<uint8_t *>(pred), pred_stride, vec_ok);
     else
         hipLaunchKernelGGL(fullpel_pred_kernel<uint16_t>, g, blk, 0, ctx->stream, static_cast<const uint16_t *>(ref), ref_stride, (int)width, (int)height,
-                           sb_best_mv, (int)list, (int)ref_idx, w64, (int)(y_lo / 16), static_cast<uint16_t *>(pred), pred_stride);
+                           sb_best_mv, (int)list, (int)ref_idx, w64, (int)b64_row_start, static_cast<uint16_t *>(pred), pred_stride, vec_ok);
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }
