@@ -148,8 +148,13 @@ class Workload:
 
 
 def cpu_baseline(wl, seconds_target=12.0):
-    """The oracle (C restatement, bit-exact to the reference `_c` path; oracle/) on the host cores: ME on a band of b64
-    rows + the RD chain on the same rows, all cores via one thread per row group (ctypes releases the GIL)."""
+    """The same work on the host cores for a bounded band of b64 rows (one row per thread; ctypes releases the GIL):
+    ME of a distance-2 picture (R = 2) + the RD chain at the three depths.
+      kind "reference": the reference's own kernels, compiled from its sources into oracle/_ref/libsvtref.so and driven by
+        oracle/ref_harness.c -- svt_aom_motion_estimation_b64 with the AVX2 / SSE4.1 SAD kernels, and the RD chain through
+        the AVX2 forward transforms / quantizer / distortions and the SSE4.1 inverse transforms (the dav1d .asm inverse
+        needs nasm, which this image lacks);
+      kind "port": the oracle (C restatement, bit-exact to the reference `_c` path) when that library is absent."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import concurrent.futures as cf
     import pyoracle
@@ -161,48 +166,54 @@ def cpu_baseline(wl, seconds_target=12.0):
     src10 = wl.y10_host[CUR]
     pred10 = wl.y10_host[CUR - d]
     qrows = np.stack([rd.quant_row_from_step(140, 176)])
+    refs8 = {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}
 
-    def work(row):
-        desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[(CUR, d)]))
-        desc.b64_row_start, desc.b64_row_count = row, 1
-        pyoracle.me_picture("oracle", cfg, desc, wl.host8[CUR], {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}, search_level=False)
-        for ts in RD_SIZES:
-            jobs = rd.grid_jobs(W, H, W, ts)
-            ys = jobs["src_offset"] // W
-            jobs = np.ascontiguousarray(jobs[(ys >= row * 64) & (ys < row * 64 + 64)])
-            rd.run_oracle(dict(bit_depth=10, quant_kind=0, tx_size=ts, src_stride=W, pred_stride=W), src10, pred10, jobs, qrows, want_coeffs=False, want_recon=False)
+    def make_work(me_impl, rd_impl):
+        def work(row):
+            desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[(CUR, d)]))
+            desc.b64_row_start, desc.b64_row_count = row, 1
+            pyoracle.me_picture(me_impl, cfg, desc, wl.host8[CUR], refs8, search_level=False)
+            for ts in RD_SIZES:
+                jobs = rd.grid_jobs(W, H, W, ts)
+                ys = jobs["src_offset"] // W
+                jobs = np.ascontiguousarray(jobs[(ys >= row * 64) & (ys < row * 64 + 64)])
+                rd.run_oracle(dict(bit_depth=10, quant_kind=0, tx_size=ts, src_stride=W, pred_stride=W), src10, pred10, jobs, qrows, want_coeffs=False,
+                              want_recon=False, impl=rd_impl)
+        return work
+
+    def timed(work, budget):
+        t0 = time.time()
+        reps = 0
+        while True:
+            with cf.ThreadPoolExecutor(cores) as ex:
+                list(ex.map(work, range(row_start, row_start + rows_total)))
+            reps += 1
+            if time.time() - t0 > budget or reps >= 8:
+                break
+        return reps * rows_total * 64 * W / (time.time() - t0) / 1e6, reps
 
     pyoracle.load_oracle()
-    t0 = time.time()
-    reps = 0
-    while True:
-        with cf.ThreadPoolExecutor(cores) as ex:
-            list(ex.map(work, range(row_start, row_start + rows_total)))
-        reps += 1
-        if time.time() - t0 > seconds_target or reps >= 8:
-            break
-    dt = time.time() - t0
-    pixels = reps * rows_total * 64 * W
-    out = {"value": round(pixels / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-           "sample": f"{reps} x {rows_total} b64 rows ({rows_total * 64}x{W} px) of the 2160p distance-2 picture: oracle ME (R=2) + RD chain at 3 depths"}
-    # informational: the reference's own AVX2 ME kernels (oracle/_ref, SAD path only), same rows, same threads
+    sample = "{reps} x {rows} b64 rows ({h}x{w} px) of the 2160p distance-2 picture: ME (R=2) + RD chain at 3 depths"
+    have_ref = False
     if pyoracle.ref_available():
         try:
             ref = pyoracle.load_ref()
-            if ref.ref_has_avx2():
-                ref.ref_set_simd(1)
-
-                def work_ref(row):
-                    desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[(CUR, d)]))
-                    desc.b64_row_start, desc.b64_row_count = row, 1
-                    pyoracle.me_picture("ref", cfg, desc, wl.host8[CUR], {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}, search_level=False)
-                t1 = time.time()
-                with cf.ThreadPoolExecutor(cores) as ex:
-                    list(ex.map(work_ref, range(row_start, row_start + rows_total)))
-                out["reference_avx2_me_only_mpixels_s"] = round(rows_total * 64 * W / (time.time() - t1) / 1e6, 2)
-                ref.ref_set_simd(0)
-        except Exception as e:  # informational only
-            out["reference_avx2_me_only_error"] = str(e)[:100]
+            have_ref = bool(ref.ref_has_avx2())
+        except Exception:
+            have_ref = False
+    if have_ref:
+        ref.ref_set_simd(1)
+        ref.ref_set_simd_rd(1)
+        v, reps = timed(make_work("ref", "ref_simd"), seconds_target)
+        ref.ref_set_simd(0)
+        out = {"value": round(v, 2), "unit": "Mpixels/s", "cores": cores, "kind": "reference",
+               "sample": sample.format(reps=reps, rows=rows_total, h=rows_total * 64, w=W) + "; reference AVX2/SSE4.1 kernels (oracle/_ref)"}
+        vp, _ = timed(make_work("oracle", "oracle"), seconds_target / 2)
+        out["port_value"] = round(vp, 2)  # informational: the oracle's plain-C restatement on the same rows
+    else:
+        v, reps = timed(make_work("oracle", "oracle"), seconds_target)
+        out = {"value": round(v, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+               "sample": sample.format(reps=reps, rows=rows_total, h=rows_total * 64, w=W) + "; oracle C restatement"}
     return out
 
 

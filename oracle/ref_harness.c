@@ -363,3 +363,112 @@ uint32_t ref_hadamard_path(uint8_t *input, uint32_t input_stride, uint8_t *pred,
     Buf2D i = {input, NULL, 0, 0, (int)input_stride}, p = {pred, NULL, 0, 0, (int)pred_stride};
     return hadamard_path_c(r, c, i, p, bsize);
 }
+
+/* =====================================================================================================================
+ * The RD chain of tx_type_search (Codec/product_coding_loop.c:4764-4934) driven through the reference's OWN kernels -- its
+ * rtcd function pointers, loaded with the `_c` bodies or with the AVX2 / SSE4.1 intrinsics the x86 dispatch would pick
+ * (Codec/common_dsp_rtcd.c:466-560, Codec/aom_dsp_rtcd.c:188-300; the dav1d .asm inverse transforms need nasm, so the inverse
+ * takes the SSE4.1 intrinsics).  Same descriptor and outputs as svt_hip_rd_batch (host pointers).  Pins oracle/rd_oracle.c
+ * as a whole chain and serves as bench.py's "reference" CPU baseline.  "b" quantizer only (what the bench runs).
+ * ===================================================================================================================== */
+#include "../include/svt_hip_dsp.h"
+
+typedef void (*FwdFn)(int16_t *, int32_t *, uint32_t, TxType, uint8_t);
+typedef void (*InvFn)(const int32_t *, uint16_t *, int32_t, uint16_t *, int32_t, TxType, int32_t);
+
+static FwdFn g_fwd[19];
+static InvFn g_inv_sq[5]; /* 4x4 .. 64x64 take the 7-argument form; the rectangular ones add tx_size and eob */
+
+void ref_set_simd_rd(int use_simd) {
+#define FWD_C(i, n) g_fwd[i] = n##_c
+    g_fwd[0] = svt_av1_transform_two_d_4x4_c; g_fwd[1] = svt_av1_transform_two_d_8x8_c; g_fwd[2] = svt_av1_transform_two_d_16x16_c;
+    g_fwd[3] = svt_av1_transform_two_d_32x32_c; g_fwd[4] = svt_av1_transform_two_d_64x64_c;
+    FWD_C(5, svt_av1_fwd_txfm2d_4x8); FWD_C(6, svt_av1_fwd_txfm2d_8x4); FWD_C(7, svt_av1_fwd_txfm2d_8x16); FWD_C(8, svt_av1_fwd_txfm2d_16x8);
+    FWD_C(9, svt_av1_fwd_txfm2d_16x32); FWD_C(10, svt_av1_fwd_txfm2d_32x16); FWD_C(11, svt_av1_fwd_txfm2d_32x64); FWD_C(12, svt_av1_fwd_txfm2d_64x32);
+    FWD_C(13, svt_av1_fwd_txfm2d_4x16); FWD_C(14, svt_av1_fwd_txfm2d_16x4); FWD_C(15, svt_av1_fwd_txfm2d_8x32); FWD_C(16, svt_av1_fwd_txfm2d_32x8);
+    FWD_C(17, svt_av1_fwd_txfm2d_16x64); FWD_C(18, svt_av1_fwd_txfm2d_64x16);
+#undef FWD_C
+    g_inv_sq[0] = svt_av1_inv_txfm2d_add_4x4_c; g_inv_sq[1] = svt_av1_inv_txfm2d_add_8x8_c; g_inv_sq[2] = svt_av1_inv_txfm2d_add_16x16_c;
+    g_inv_sq[3] = svt_av1_inv_txfm2d_add_32x32_c; g_inv_sq[4] = svt_av1_inv_txfm2d_add_64x64_c;
+    svt_residual_kernel8bit           = svt_residual_kernel8bit_c;
+    svt_residual_kernel16bit          = svt_residual_kernel16bit_c;
+    svt_aom_satd                      = svt_aom_satd_c;
+    svt_aom_highbd_quantize_b         = svt_aom_highbd_quantize_b_c;
+    svt_aom_quantize_b                = svt_aom_quantize_b_c_ii;
+    svt_full_distortion_kernel32_bits = svt_full_distortion_kernel32_bits_c;
+    svt_full_distortion_kernel16_bits = svt_full_distortion_kernel16_bits_c;
+    svt_spatial_full_distortion_kernel = svt_spatial_full_distortion_kernel_c;
+    svt_handle_transform64x64 = svt_handle_transform64x64_c; svt_handle_transform64x32 = svt_handle_transform64x32_c;
+    svt_handle_transform32x64 = svt_handle_transform32x64_c; svt_handle_transform64x16 = svt_handle_transform64x16_c;
+    svt_handle_transform16x64 = svt_handle_transform16x64_c;
+#ifdef REF_WITH_AVX2
+    if (use_simd) { /* the picks of svt_aom_setup_common_rtcd_internal / svt_aom_setup_rtcd_internal with AVX2 available, minus .asm */
+        g_fwd[0] = svt_av1_fwd_txfm2d_4x4_sse4_1; g_fwd[1] = svt_av1_fwd_txfm2d_8x8_avx2; g_fwd[2] = svt_av1_fwd_txfm2d_16x16_avx2;
+        g_fwd[3] = svt_av1_fwd_txfm2d_32x32_avx2; g_fwd[4] = svt_av1_fwd_txfm2d_64x64_avx2;
+        g_inv_sq[0] = svt_av1_inv_txfm2d_add_4x4_sse4_1; g_inv_sq[1] = svt_av1_inv_txfm2d_add_8x8_sse4_1; g_inv_sq[2] = svt_av1_inv_txfm2d_add_16x16_sse4_1;
+        g_inv_sq[3] = svt_av1_inv_txfm2d_add_32x32_sse4_1; g_inv_sq[4] = svt_av1_inv_txfm2d_add_64x64_sse4_1;
+        svt_residual_kernel16bit          = svt_residual_kernel16bit_avx2;
+        svt_aom_highbd_quantize_b         = svt_aom_highbd_quantize_b_avx2;
+        svt_full_distortion_kernel32_bits = svt_full_distortion_kernel32_bits_avx2;
+        svt_full_distortion_kernel16_bits = svt_full_distortion_kernel16_bits_avx2;
+        svt_handle_transform64x64         = svt_handle_transform64x64_avx2;
+    }
+#else
+    (void)use_simd;
+#endif
+}
+
+int ref_rd_batch(const SvtHipRdBatchDesc *d) {
+    const int ts = d->tx_size;
+    if (!g_fwd[0]) ref_set_simd_rd(0);
+    if (ts < 0 || ts > 4 || d->quant_kind != 0) return 2; /* square sizes, "b" quantizer */
+    const int W = tx_size_wide[ts], H = tx_size_high[ts], WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
+    const int bd = d->bit_depth, hbd = bd != 8, log_scale = av1_get_tx_scale_tab[ts];
+    int16_t  *res = aligned_alloc(64, sizeof(int16_t) * W * H);
+    int32_t  *co = aligned_alloc(64, sizeof(int32_t) * W * H), *q = aligned_alloc(64, sizeof(int32_t) * W * H), *dq = aligned_alloc(64, sizeof(int32_t) * W * H);
+    uint16_t *p16 = aligned_alloc(64, sizeof(uint16_t) * W * H), *r16 = aligned_alloc(64, sizeof(uint16_t) * W * H);
+    for (uint32_t j = 0; j < d->n_jobs; j++) {
+        const SvtHipTxJob    *jb = &d->jobs[j];
+        const SvtHipQuantRow *qr = &d->quant_rows[jb->quant_row];
+        const TxType          tt = (TxType)(jb->tx_type & 15);
+        /* MacroblockPlane rows are int16[8], 16-byte aligned: [0] = DC, [1..7] = AC (full_loop.c:1627-1685) */
+        DECLARE_ALIGNED(16, int16_t, zbin[8]); DECLARE_ALIGNED(16, int16_t, rnd[8]); DECLARE_ALIGNED(16, int16_t, qnt[8]);
+        DECLARE_ALIGNED(16, int16_t, qsh[8]); DECLARE_ALIGNED(16, int16_t, deq[8]);
+        for (int k = 0; k < 8; k++) { zbin[k] = qr->zbin[k != 0]; rnd[k] = qr->round[k != 0]; qnt[k] = qr->quant[k != 0]; qsh[k] = qr->quant_shift[k != 0]; deq[k] = qr->dequant[k != 0]; }
+        if (hbd) svt_residual_kernel16bit((uint16_t *)d->src + jb->src_offset, d->src_stride, (uint16_t *)d->pred + jb->pred_offset, d->pred_stride, res, W, W, H);
+        else svt_residual_kernel8bit((uint8_t *)d->src + jb->src_offset, d->src_stride, (uint8_t *)d->pred + jb->pred_offset, d->pred_stride, res, W, W, H);
+        g_fwd[ts](res, co, W, tt, (uint8_t)bd);
+        d->three_quad_energy[j] = ts == 4 ? svt_handle_transform64x64(co) : 0;
+        d->satd[j]              = (uint32_t)svt_aom_satd(co, NP);
+        const ScanOrder *so = &av1_scan_orders[ts][tt];
+        if (hbd) svt_aom_highbd_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
+        else svt_aom_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
+        uint64_t dist[DIST_CALC_TOTAL];
+        svt_full_distortion_kernel32_bits(co, WP, dq, WP, dist, WP, HP);
+        d->dist_coeff[2 * (size_t)j] = dist[DIST_CALC_RESIDUAL]; d->dist_coeff[2 * (size_t)j + 1] = dist[DIST_CALC_PREDICTION];
+        for (int r = 0; r < H; r++)
+            for (int c = 0; c < W; c++)
+                p16[r * W + c] = hbd ? ((const uint16_t *)d->pred)[jb->pred_offset + (size_t)r * d->pred_stride + c]
+                                     : ((const uint8_t *)d->pred)[jb->pred_offset + (size_t)r * d->pred_stride + c];
+        g_inv_sq[ts](dq, p16, W, r16, W, tt, bd);
+        uint64_t sse;
+        if (hbd) sse = svt_full_distortion_kernel16_bits((uint8_t *)((uint16_t *)d->src + jb->src_offset), 0, d->src_stride, (uint8_t *)r16, 0, W, W, H);
+        else {
+            sse = 0;
+            for (int r = 0; r < H; r++)
+                for (int c = 0; c < W; c++) { const int64_t e = (int64_t)((const uint8_t *)d->src)[jb->src_offset + (size_t)r * d->src_stride + c] - r16[r * W + c]; sse += (uint64_t)(e * e); }
+        }
+        d->sse[j] = sse;
+        if (d->recon)
+            for (int r = 0; r < H; r++)
+                for (int c = 0; c < W; c++) {
+                    if (hbd) ((uint16_t *)d->recon)[jb->pred_offset + (size_t)r * d->pred_stride + c] = r16[r * W + c];
+                    else ((uint8_t *)d->recon)[jb->pred_offset + (size_t)r * d->pred_stride + c] = (uint8_t)r16[r * W + c];
+                }
+        if (d->coeff) memcpy(d->coeff + (size_t)j * NP, co, sizeof(int32_t) * NP);
+        if (d->qcoeff) memcpy(d->qcoeff + (size_t)j * NP, q, sizeof(int32_t) * NP);
+        if (d->dqcoeff) memcpy(d->dqcoeff + (size_t)j * NP, dq, sizeof(int32_t) * NP);
+    }
+    free(res); free(co); free(q); free(dq); free(p16); free(r16);
+    return 0;
+}

@@ -224,3 +224,34 @@ def test_partial_frequency_transforms_are_masked_full_transforms(ref, oracle, ts
                 f2[H >> sh:, :] = 0
                 f2[:, W >> sh:] = 0
                 assert np.array_equal(f2.reshape(-1), part), (nm, shape, tt, bd)
+
+
+@pytest.mark.parametrize("impl", ["ref", "ref_simd"])
+@pytest.mark.parametrize("ts", range(5))
+def test_rd_chain_oracle_equals_reference_chain(ref, oracle, ts, impl):
+    """The whole tx_type_search iteration (residual -> fwd txfm -> SATD -> quantize_b -> coefficient distortion -> inv txfm
+    -> SSE) through the reference's own kernels (`_c`, and the AVX2 / SSE4.1 intrinsics its x86 dispatch installs) against
+    oracle/rd_oracle.c: every output of svt_hip_rd_batch, square sizes, 8 and 10 bit."""
+    from svt_av1_psyex_amd import rd
+    from txfm_cases import valid_types
+    rng = np.random.default_rng(70 + ts)
+    rows = np.stack([rd.quant_row_from_step(8, 10), rd.quant_row_from_step(60, 75), rd.quant_row_from_step(500, 640)])
+    for bd in (8, 10):
+        hi = (1 << bd) - 1
+        dt = np.uint8 if bd == 8 else np.uint16
+        for pattern in ("smooth", "random"):
+            if pattern == "smooth":
+                base = np.kron(rng.integers(0, hi + 1, (18, 26)).astype(np.float64), np.ones((8, 8)))[:128, :192]
+                src = np.clip(base + rng.normal(0, 6 * (1 << (bd - 8)), base.shape), 0, hi).astype(dt)
+                pred = np.clip(base + rng.normal(0, 3 * (1 << (bd - 8)), base.shape), 0, hi).astype(dt)
+            else:
+                src = rng.integers(0, hi + 1, (128, 192)).astype(dt); pred = rng.integers(0, hi + 1, (128, 192)).astype(dt)
+            jobs = rd.grid_jobs(192, 128, 192, ts)
+            types = [t for t in valid_types(ts) if not (impl == "ref_simd" and ts == 3 and t not in (0, 9))]  # the SSE4.1 32x32 inverse handles DCT_DCT / IDTX only
+            jobs["tx_type"] = rng.choice(types, len(jobs))
+            jobs["quant_row"] = rng.integers(0, 3, len(jobs))
+            f = dict(bit_depth=bd, quant_kind=0, tx_size=ts, src_stride=192, pred_stride=192)
+            a = rd.run_oracle(f, src, pred, jobs, rows)
+            b = rd.run_oracle(f, src, pred, jobs, rows, impl=impl)
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (ts, bd, pattern, k, np.argwhere(a[k] != b[k])[:3].tolist())
