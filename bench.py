@@ -168,15 +168,20 @@ def cpu_baseline(wl, seconds_target=12.0):
     qrows = np.stack([rd.quant_row_from_step(140, 176)])
     refs8 = {(0, 0): wl.host8[CUR - d], (1, 0): wl.host8[CUR + d]}
 
+    row_jobs = {}  # (row, tx_size) -> job list, built outside the timed region
+    for ts in RD_SIZES:
+        alljobs = rd.grid_jobs(W, H, W, ts)
+        ys = alljobs["src_offset"] // W
+        for row in range(row_start, row_start + rows_total):
+            row_jobs[(row, ts)] = np.ascontiguousarray(alljobs[(ys >= row * 64) & (ys < row * 64 + 64)])
+
     def make_work(me_impl, rd_impl):
         def work(row):
             desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[(CUR, d)]))
             desc.b64_row_start, desc.b64_row_count = row, 1
             pyoracle.me_picture(me_impl, cfg, desc, wl.host8[CUR], refs8, search_level=False)
             for ts in RD_SIZES:
-                jobs = rd.grid_jobs(W, H, W, ts)
-                ys = jobs["src_offset"] // W
-                jobs = np.ascontiguousarray(jobs[(ys >= row * 64) & (ys < row * 64 + 64)])
+                jobs = row_jobs[(row, ts)]
                 rd.run_oracle(dict(bit_depth=10, quant_kind=0, tx_size=ts, src_stride=W, pred_stride=W), src10, pred10, jobs, qrows, want_coeffs=False,
                               want_recon=False, impl=rd_impl)
         return work
