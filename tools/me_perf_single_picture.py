@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'tests')
+sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 import numpy as np, torch, ctypes as C
 from me_cases import MeCase, compare
 from svt_av1_psyex_amd import api, abi

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0,'tests')
+sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 import numpy as np, ctypes as C
 import me_cases
 from svt_av1_psyex_amd import api, abi
