@@ -68,6 +68,31 @@ int  svt_aom_satd_hip(const int32_t *coeff, int length);
  * square block of `block_size_wide` (4..128) */
 uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide);
 
+/* svt_aom_sad{W}x{H} / svt_aom_sad{W}x{H}x4d (aom_dsp_rtcd.h:267-347; C_DEFAULT/compute_sad_c.c:117-207) */
+#define SVT_HIP_DECL_SAD(W, H)                                                                                          \
+    uint32_t svt_aom_sad##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride);          \
+    void svt_aom_sad##W##x##H##x4d_hip(const uint8_t *src, int src_stride, const uint8_t *const ref[], int ref_stride, uint32_t *sad_array);
+SVT_HIP_DECL_SAD(4, 4) SVT_HIP_DECL_SAD(4, 8) SVT_HIP_DECL_SAD(4, 16) SVT_HIP_DECL_SAD(8, 4) SVT_HIP_DECL_SAD(8, 8) SVT_HIP_DECL_SAD(8, 16)
+SVT_HIP_DECL_SAD(8, 32) SVT_HIP_DECL_SAD(16, 4) SVT_HIP_DECL_SAD(16, 8) SVT_HIP_DECL_SAD(16, 16) SVT_HIP_DECL_SAD(16, 32) SVT_HIP_DECL_SAD(16, 64)
+SVT_HIP_DECL_SAD(32, 8) SVT_HIP_DECL_SAD(32, 16) SVT_HIP_DECL_SAD(32, 32) SVT_HIP_DECL_SAD(32, 64) SVT_HIP_DECL_SAD(64, 16) SVT_HIP_DECL_SAD(64, 32)
+SVT_HIP_DECL_SAD(64, 64) SVT_HIP_DECL_SAD(64, 128) SVT_HIP_DECL_SAD(128, 64) SVT_HIP_DECL_SAD(128, 128)
+#undef SVT_HIP_DECL_SAD
+/* svt_aom_variance_highbd_c (C_DEFAULT/variance.c:278-296) */
+uint32_t svt_aom_variance_highbd_hip(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse);
+
+/* coefficient-domain distortion (common_dsp_rtcd.h:160-161, aom_dsp_rtcd.h:212), residual (common_dsp_rtcd.h:157,170) */
+void    svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride,
+                                              uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height);
+void    svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height);
+int64_t svt_av1_block_error_hip(const int32_t *coeff, const int32_t *dqcoeff, intptr_t block_size, int64_t *ssz);
+void    svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
+                                    uint32_t area_width, uint32_t area_height);
+void    svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
+                                     uint32_t area_width, uint32_t area_height);
+/* svt_aom_estimate_transform (Codec/transforms.c:3158-3225) minus its pcs / ctx arguments: residual -> packed coefficients
+ * (min(W,32) x min(H,32)) and the energy of the discarded frequencies; pf_shape 0..3 = DEFAULT / N2 / N4 / ONLY_DC */
+int svt_hip_estimate_transform(int16_t *residual, uint32_t residual_stride, int32_t *coeff, int tx_size, uint64_t *three_quad_energy, int tx_type, int pf_shape);
+
 /* PSYEX psy-RD term (Codec/psy_rd.h:23-33): integer energies, and the fp64-scaled form */
 uint64_t svt_psy_distortion_hip(const uint8_t *input, uint32_t input_stride, const uint8_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height);
 uint64_t svt_psy_distortion_hbd_hip(const uint16_t *input, uint32_t input_stride, const uint16_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height);

@@ -362,6 +362,37 @@ __global__ void __launch_bounds__(64) satd_kernel(const int32_t *coeff, int n, i
     if (threadIdx.x == 0) *out = acc;
 }
 
+// ---- coefficient-domain distortion (svt_full_distortion_kernel32_bits_c / _cbf_zero32_bits_c, pic_operators.c:150-222;
+// svt_av1_block_error_c, common_dsp_rtcd.c:79-91): out[0] = sum (coeff - recon)^2 (recon == nullptr: 0), out[1] = sum coeff^2
+// wrap32: svt_av1_block_error_c squares with SQR() on `int` operands -- a 32-bit wrapping product, widened afterwards
+__global__ void __launch_bounds__(256) coeff_dist_kernel(const int32_t *coeff, uint32_t cstride, const int32_t *recon, uint32_t rstride, int w, int h, u64 *out,
+                                                         int wrap32) {
+    u64 d = 0, e = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int r = i / w, c = i - r * w;
+        const i64 a = coeff[(size_t)r * cstride + c];
+        if (wrap32) {
+            const uint32_t t = (uint32_t)a - (uint32_t)(recon ? recon[(size_t)r * rstride + c] : 0), ua = (uint32_t)a;
+            d += (u64)(i64)(int32_t)(t * t);
+            e += (u64)(i64)(int32_t)(ua * ua);
+            continue;
+        }
+        if (recon) { const i64 t = a - recon[(size_t)r * rstride + c]; d += (u64)(t * t); }
+        e += (u64)(a * a);
+    }
+    d = wave_sum(d); e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], d); atomicAdd(&out[1], e); }
+}
+
+// ---- residual (svt_residual_kernel8bit_c / 16bit_c, pic_operators.c:101-148): int16 arithmetic like the reference
+template <typename Pix> __global__ void __launch_bounds__(256) residual_kernel(const Pix *in, uint32_t in_stride, const Pix *pred, uint32_t pred_stride, int16_t *res,
+                                                                               uint32_t res_stride, int w, int h) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int r = i / w, c = i - r * w;
+        res[(size_t)r * res_stride + c] = (int16_t)((int16_t)in[(size_t)r * in_stride + c] - (int16_t)pred[(size_t)r * pred_stride + c]);
+    }
+}
+
 // ---- process-global context of the pointer-level entries -----------------------------------------------------------
 SvtHipContext *g_leaf_ctx = nullptr;
 std::mutex     g_leaf_mutex; // the reference calls its kernels from many threads; these entries serialise on one stream
@@ -604,6 +635,130 @@ int svt_aom_satd_hip(const int32_t *coeff, int length) {
     leaf_check(ctx, hipMemcpyAsync(&out, base + cb, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return out;
+}
+
+
+// svt_aom_sad{W}x{H} and the four-reference form (aom_dsp_rtcd.h:267-347; macros at C_DEFAULT/compute_sad_c.c:117-207)
+#define SVT_HIP_SAD(W, H)                                                                                                              \
+    uint32_t svt_aom_sad##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride) {                     \
+        return leaf_stats(src, (size_t)src_stride, ref, (size_t)ref_stride, W, H, 8, false).sad;                                        \
+    }                                                                                                                                  \
+    void svt_aom_sad##W##x##H##x4d_hip(const uint8_t *src, int src_stride, const uint8_t *const ref[], int ref_stride, uint32_t *sad_array) { \
+        for (int i = 0; i < 4; i++) sad_array[i] = leaf_stats(src, (size_t)src_stride, ref[i], (size_t)ref_stride, W, H, 8, false).sad; \
+    }
+SVT_HIP_SAD(4, 4) SVT_HIP_SAD(4, 8) SVT_HIP_SAD(4, 16) SVT_HIP_SAD(8, 4) SVT_HIP_SAD(8, 8) SVT_HIP_SAD(8, 16) SVT_HIP_SAD(8, 32)
+SVT_HIP_SAD(16, 4) SVT_HIP_SAD(16, 8) SVT_HIP_SAD(16, 16) SVT_HIP_SAD(16, 32) SVT_HIP_SAD(16, 64) SVT_HIP_SAD(32, 8) SVT_HIP_SAD(32, 16)
+SVT_HIP_SAD(32, 32) SVT_HIP_SAD(32, 64) SVT_HIP_SAD(64, 16) SVT_HIP_SAD(64, 32) SVT_HIP_SAD(64, 64) SVT_HIP_SAD(64, 128) SVT_HIP_SAD(128, 64)
+SVT_HIP_SAD(128, 128)
+#undef SVT_HIP_SAD
+
+uint32_t svt_aom_variance_highbd_hip(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse) {
+    const StatsOut o = leaf_stats(a, (size_t)a_stride, b, (size_t)b_stride, w, h, 10, false);
+    *sse = o.var_sse;
+    return o.variance;
+}
+
+static void leaf_coeff_dist(const int32_t *coeff, uint32_t cstride, const int32_t *recon, uint32_t rstride, uint32_t w, uint32_t h, uint64_t out[2], int wrap32 = 0) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    out[0] = out[1] = 0;
+    if (!w || !h) return;
+    const size_t cb = align256((((size_t)h - 1) * cstride + w) * 4), rb = recon ? align256((((size_t)h - 1) * rstride + w) * 4) : 0;
+    uint8_t *base = leaf_scratch(ctx, cb + rb + 256);
+    leaf_check(ctx, hipMemcpyAsync(base, coeff, (((size_t)h - 1) * cstride + w) * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    if (recon) leaf_check(ctx, hipMemcpyAsync(base + cb, recon, (((size_t)h - 1) * rstride + w) * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    u64 *d_out = reinterpret_cast<u64 *>(base + cb + rb);
+    leaf_check(ctx, hipMemsetAsync(d_out, 0, 16, ctx->stream), "hipMemsetAsync");
+    const int n = (int)(w * h), grid = n < 256 * 64 ? (n + 255) / 256 : 64;
+    hipLaunchKernelGGL(coeff_dist_kernel, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const int32_t *>(base), cstride,
+                       recon ? reinterpret_cast<const int32_t *>(base + cb) : nullptr, rstride, (int)w, (int)h, d_out, wrap32);
+    leaf_check(ctx, hipGetLastError(), "coeff_dist_kernel launch");
+    leaf_check(ctx, hipMemcpyAsync(out, d_out, 16, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+void svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                           uint32_t area_width, uint32_t area_height) {
+    leaf_coeff_dist(coeff, coeff_stride, recon_coeff, recon_coeff_stride, area_width, area_height, distortion_result);
+}
+void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) {
+    uint64_t o[2];
+    leaf_coeff_dist(coeff, coeff_stride, nullptr, 0, area_width, area_height, o);
+    distortion_result[0] = o[1]; // DIST_CALC_RESIDUAL = DIST_CALC_PREDICTION = sum coeff^2 (pic_operators.c:202-222)
+    distortion_result[1] = o[1];
+}
+int64_t svt_av1_block_error_hip(const int32_t *coeff, const int32_t *dqcoeff, intptr_t block_size, int64_t *ssz) {
+    uint64_t o[2];
+    leaf_coeff_dist(coeff, (uint32_t)block_size, dqcoeff, (uint32_t)block_size, (uint32_t)block_size, 1, o, 1);
+    *ssz = (int64_t)o[1];
+    return (int64_t)o[0];
+}
+
+} // extern "C"
+template <typename Pix> static void leaf_residual(const Pix *in, uint32_t in_stride, const Pix *pred, uint32_t pred_stride, int16_t *res, uint32_t res_stride, uint32_t w, uint32_t h) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    if (!w || !h) return;
+    const size_t ib = align256((((size_t)h - 1) * in_stride + w) * sizeof(Pix)), pb = align256((((size_t)h - 1) * pred_stride + w) * sizeof(Pix));
+    const size_t rbytes = (((size_t)h - 1) * res_stride + w) * 2;
+    uint8_t *base = leaf_scratch(ctx, ib + pb + align256(rbytes));
+    leaf_check(ctx, hipMemcpyAsync(base, in, (((size_t)h - 1) * in_stride + w) * sizeof(Pix), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(base + ib, pred, (((size_t)h - 1) * pred_stride + w) * sizeof(Pix), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    // the rows between the block's columns belong to the caller: bring them over so that the copy back leaves them unchanged
+    leaf_check(ctx, hipMemcpyAsync(base + ib + pb, res, rbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    const int n = (int)(w * h), grid = n < 256 * 64 ? (n + 255) / 256 : 64;
+    hipLaunchKernelGGL(residual_kernel<Pix>, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const Pix *>(base), in_stride, reinterpret_cast<const Pix *>(base + ib),
+                       pred_stride, reinterpret_cast<int16_t *>(base + ib + pb), res_stride, (int)w, (int)h);
+    leaf_check(ctx, hipGetLastError(), "residual_kernel launch");
+    leaf_check(ctx, hipMemcpyAsync(res, base + ib + pb, rbytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+extern "C" {
+void svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
+                                 uint32_t area_width, uint32_t area_height) {
+    leaf_residual<uint8_t>(input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height);
+}
+void svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
+                                  uint32_t area_width, uint32_t area_height) {
+    leaf_residual<uint16_t>(input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height);
+}
+
+// svt_aom_estimate_transform (Codec/transforms.c:3158-3225) without the pcs / ctx arguments (they only select the lossless WHT):
+// int16 residual -> packed coefficients (min(W,32) x min(H,32)) + the energy of the discarded frequencies, through the fused
+// RD kernel (a uint16 plane holding the residual's bit pattern against an all-zero prediction reproduces the residual exactly)
+int svt_hip_estimate_transform(int16_t *residual, uint32_t residual_stride, int32_t *coeff, int tx_size, uint64_t *three_quad_energy, int tx_type, int pf_shape) {
+    if (tx_size < 0 || tx_size >= SVT_HIP_TX_SIZES_ALL || tx_type < 0 || tx_type >= SVT_HIP_TX_TYPES || pf_shape < 0 || pf_shape > 3 || !residual || !coeff) return SVT_HIP_ERR_BAD_PARAM;
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    const int W = svt_hip_tx_size_wide(tx_size), H = svt_hip_tx_size_high(tx_size), NP = (W > 32 ? 32 : W) * (H > 32 ? 32 : H);
+    const size_t sb = align256((((size_t)H - 1) * residual_stride + W) * 2), zb = align256((size_t)W * H * 2);
+    uint8_t *base = leaf_scratch(ctx, sb + zb + 256 + 256 + 256 + align256((size_t)NP * 4));
+    uint8_t *d_src = base, *d_zero = d_src + sb, *d_job = d_zero + zb, *d_row = d_job + 256, *d_out = d_row + 256, *d_coeff = d_out + 256;
+    leaf_check(ctx, hipMemcpyAsync(d_src, residual, (((size_t)H - 1) * residual_stride + W) * 2, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemsetAsync(d_zero, 0, zb, ctx->stream), "hipMemsetAsync");
+    SvtHipTxJob job;
+    memset(&job, 0, sizeof(job));
+    job.tx_type = (uint8_t)tx_type; job.pf_shape = (uint8_t)pf_shape;
+    SvtHipQuantRow row;
+    memset(&row, 0, sizeof(row));
+    for (int k = 0; k < 2; k++) { row.zbin[k] = 32767; row.quant[k] = 1; row.quant_shift[k] = 1; row.dequant[k] = 1; } // quantizer output unused
+    leaf_check(ctx, hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_row, &row, sizeof(row), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    SvtHipRdBatchDesc d;
+    memset(&d, 0, sizeof(d));
+    d.bit_depth = 10; d.quant_kind = 0; d.tx_size = (uint8_t)tx_size; d.n_jobs = 1; d.src_stride = residual_stride; d.pred_stride = (uint32_t)W;
+    d.src = d_src; d.pred = d_zero; d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.quant_rows = reinterpret_cast<const SvtHipQuantRow *>(d_row); d.n_quant_rows = 1;
+    d.eob = reinterpret_cast<uint16_t *>(d_out); d.satd = reinterpret_cast<uint32_t *>(d_out + 8); d.dist_coeff = reinterpret_cast<uint64_t *>(d_out + 16);
+    d.three_quad_energy = reinterpret_cast<uint64_t *>(d_out + 32); d.sse = reinterpret_cast<uint64_t *>(d_out + 40); d.coeff = reinterpret_cast<int32_t *>(d_coeff);
+    if (svt_hip_rd_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    leaf_check(ctx, hipMemcpyAsync(coeff, d_coeff, (size_t)NP * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    uint64_t tq = 0;
+    leaf_check(ctx, hipMemcpyAsync(&tq, d_out + 32, 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if (three_quad_energy) *three_quad_energy = tq;
+    return SVT_HIP_OK;
 }
 
 } // extern "C"

@@ -178,3 +178,68 @@ def test_leaf_sub_pixel_variance(leaf, oracle):
             x = getattr(leaf, f"svt_aom_sub_pixel_variance{w}x{h}_hip")(p(a), w + 4, xo, yo, p(b), w + 2, C.byref(s1)) & 0xFFFFFFFF
             y = oracle.orc_sub_pixel_variance8(p(a), w + 4, xo, yo, p(b), w + 2, w, h, C.byref(s2)) & 0xFFFFFFFF
             assert (x, s1.value) == (y, s2.value), (w, h, xo, yo)
+
+
+def test_leaf_fixed_size_sad_and_highbd_variance(leaf, oracle):
+    rng = np.random.default_rng(51)
+    for (w, h) in abi.VARIANCE_SIZES:
+        a = rng.integers(0, 256, (h, w + 3)).astype(np.uint8)
+        refs = [rng.integers(0, 256, (h, w + 8)).astype(np.uint8) for _ in range(4)]
+        want = [oracle.orc_nxm_sad(p(a), C.c_uint32(w + 3), p(r), C.c_uint32(w + 8), C.c_uint32(h), C.c_uint32(w)) for r in refs]
+        assert getattr(leaf, f"svt_aom_sad{w}x{h}_hip")(p(a), w + 3, p(refs[0]), w + 8) == want[0]
+        ptrs = (C.c_void_p * 4)(*[r.ctypes.data for r in refs])
+        out = (C.c_uint32 * 4)()
+        getattr(leaf, f"svt_aom_sad{w}x{h}x4d_hip")(p(a), w + 3, ptrs, w + 8, out)
+        assert list(out) == want
+    a16 = rng.integers(0, 1024, (32, 40)).astype(np.uint16); b16 = rng.integers(0, 1024, (32, 36)).astype(np.uint16)
+    s1, s2 = C.c_uint32(), C.c_uint32()
+    assert leaf.svt_aom_variance_highbd_hip(p(a16), 40, p(b16), 36, 32, 32, C.byref(s1)) & 0xFFFFFFFF == oracle.orc_variance16(p(a16), 40, p(b16), 36, 32, 32, C.byref(s2)) & 0xFFFFFFFF
+    assert s1.value == s2.value
+
+
+def test_leaf_coefficient_distortion_residual_and_estimate_transform(leaf, oracle):
+    rng = np.random.default_rng(52)
+    leaf.svt_av1_block_error_hip.restype = C.c_int64
+    oracle.orc_block_error.restype = C.c_int64
+    for (w, h) in [(4, 4), (16, 8), (32, 32), (64, 64)]:
+        co = rng.integers(-(1 << 20), 1 << 20, (h, w + 2)).astype(np.int32); rc = (co + rng.integers(-300, 300, co.shape)).astype(np.int32)
+        a, b = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        leaf.svt_full_distortion_kernel32_bits_hip(p(co), C.c_uint32(w + 2), p(rc), C.c_uint32(w + 2), a, C.c_uint32(w), C.c_uint32(h))
+        oracle.orc_full_distortion32(p(co), C.c_uint32(w + 2), p(rc), C.c_uint32(w + 2), b, C.c_uint32(w), C.c_uint32(h))
+        assert list(a) == list(b)
+        leaf.svt_full_distortion_kernel_cbf_zero32_bits_hip(p(co), C.c_uint32(w + 2), a, C.c_uint32(w), C.c_uint32(h))
+        oracle.orc_full_distortion32_cbf_zero(p(co), C.c_uint32(w + 2), b, C.c_uint32(w), C.c_uint32(h))
+        assert list(a) == list(b)
+        flat, flat2 = np.ascontiguousarray(co[:, :w]).reshape(-1), np.ascontiguousarray(rc[:, :w]).reshape(-1)
+        z1, z2 = C.c_int64(), C.c_int64()
+        assert leaf.svt_av1_block_error_hip(p(flat), p(flat2), C.c_ssize_t(flat.size), C.byref(z1)) == oracle.orc_block_error(p(flat), p(flat2), C.c_ssize_t(flat.size), C.byref(z2))
+        assert z1.value == z2.value
+        for bd, dt, fn, fo in ((8, np.uint8, "svt_residual_kernel8bit_hip", "orc_residual8"), (10, np.uint16, "svt_residual_kernel16bit_hip", "orc_residual16")):
+            x = rng.integers(0, 1 << bd, (h, w + 3)).astype(dt); y = rng.integers(0, 1 << bd, (h, w + 5)).astype(dt)
+            r1 = np.full((h, w + 1), 77, np.int16); r2 = r1.copy()
+            getattr(leaf, fn)(p(x), C.c_uint32(w + 3), p(y), C.c_uint32(w + 5), p(r1), C.c_uint32(w + 1), C.c_uint32(w), C.c_uint32(h))
+            getattr(oracle, fo)(p(x), C.c_uint32(w + 3), p(y), C.c_uint32(w + 5), p(r2), C.c_uint32(w + 1), C.c_uint32(w), C.c_uint32(h))
+            assert np.array_equal(r1, r2)
+    # svt_hip_estimate_transform == forward transform + 64-point repack / energy of the oracle, any int16 residual, every pf_shape
+    from txfm_cases import TX_H, TX_W, valid_types
+    oracle.orc_handle_transform.restype = C.c_uint64
+    for ts in (0, 2, 4, 9, 12, 17):
+        W, H = TX_W[ts], TX_H[ts]
+        for tt in valid_types(ts)[:3]:
+            for pf in range(4):
+                res = rng.integers(-32768, 32768, (H, W + 3)).astype(np.int16)
+                got = np.zeros(min(W, 32) * min(H, 32), np.int32); tq = C.c_uint64()
+                assert leaf.svt_hip_estimate_transform(p(res), C.c_uint32(W + 3), p(got), ts, C.byref(tq), tt, pf) == 0
+                full = np.zeros(W * H, np.int32)
+                oracle.orc_fwd_txfm2d(p(res), p(full), C.c_uint32(W + 3), C.c_int(tt), C.c_int(ts))
+                if pf:
+                    f2 = full.reshape(H, W)
+                    keep = np.zeros((H, W), bool)
+                    if pf == 3:
+                        keep[0, 0] = True
+                    else:
+                        keep[:H >> pf, :W >> pf] = True
+                    f2[~keep] = 0
+                e = oracle.orc_handle_transform(p(full), C.c_int(ts))
+                assert np.array_equal(got, full[:got.size]), (ts, tt, pf)
+                assert tq.value == (0 if pf else e), (ts, tt, pf)
