@@ -532,9 +532,10 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
     }
 }
 
+// slot < 0: append (serial pushes by lane 0); otherwise the caller owns st.req[slot] and sets st.nreq itself (lane-parallel pushes)
 __device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t stride, int sa_w, int sa_h, int bw, int bh, int rs,
-                                         int level, int skip) {
-    Req &r      = st.req[st.nreq++];
+                                         int level, int skip, int slot = -1) {
+    Req &r      = st.req[slot >= 0 ? slot : st.nreq++];
     r.win       = win;
     r.stride    = stride;
     r.sa_w      = (int16_t)sa_w;
@@ -548,9 +549,9 @@ __device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t st
 
 // The svt_sad_loop_kernel call made by the HME levels and pre-HME (e.g. motion_estimation.c:891-909)
 __device__ __forceinline__ void push_hme_req(St &st, CParams &p, int level, CPlane &rp, int org_x, int org_y,
-                                             int bw, int bh, int ox, int oy, int sa_w, int sa_h, int skip) {
+                                             int bw, int bh, int ox, int oy, int sa_w, int sa_h, int skip, int slot = -1) {
     const int full = (p.cfg.hme_search_method == 1);
-    push_req(st, plane_at(rp, org_x + ox, org_y + oy), rp.stride, sa_w, sa_h, bw, full ? bh : (bh >> 1), full ? 1 : 2, level, skip);
+    push_req(st, plane_at(rp, org_x + ox, org_y + oy), rp.stride, sa_w, sa_h, bw, full ? bh : (bh >> 1), full ? 1 : 2, level, skip, slot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -696,12 +697,16 @@ __device__ void set_hme_all(St &st, CParams &p, int lvl, int li, int ri, int x, 
 }
 
 // get_hme_l0_search_area, motion_estimation.c:1800-1868
-__device__ void hme_l0_search_area(St &st, CParams &p, int li, int ri, uint32_t dist, int &sa_w, int &sa_h) {
+// Works on a copy of the block's total level-0 area (the reference divides its context's copy in place and restores it after
+// each reference, motion_estimation.c:1948-1953,2031-2034: every reference starts from the same base)
+__device__ void hme_l0_search_area(const St &cst, CParams &p, int li, int ri, uint32_t dist, int &sa_w, int &sa_h) {
+    struct { SvtHipSearchAreaMinMax hme_l0_sa; } st = {cst.hme_l0_sa};
+    const int16_t (*hx0)[4][2][2] = cst.hx[0], (*hy0)[4][2][2] = cst.hy[0];
     auto &c = p.cfg;
     if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) {
         int is_hor = 1, is_ver = 1, is_still = 0;
         if (c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max && (li || ri)) {
-            const int mvx = st.hx[0][0][0][0][0], mvy = st.hy[0][0][0][0][0];
+            const int mvx = hx0[0][0][0][0], mvy = hy0[0][0][0][0];
             is_ver   = iabs(mvx) < c.reduce_hme_l0_sr_th_min && iabs(mvy) > c.reduce_hme_l0_sr_th_max;
             is_hor   = iabs(mvx) > c.reduce_hme_l0_sr_th_max && iabs(mvy) < c.reduce_hme_l0_sr_th_min;
             is_still = iabs(mvx) < c.reduce_hme_l0_sr_th_min * 3 && iabs(mvy) < c.reduce_hme_l0_sr_th_min * 3;
@@ -726,7 +731,7 @@ struct HmeGeom { int16_t ox, oy; };
 
 // hme_level_0/1/2 geometry (motion_estimation.c:820-1113): pushes the search and returns its origin
 __device__ HmeGeom push_hme_level(St &st, CParams &p, int level, CPlane &rp, int org_x, int org_y, int bw, int bh,
-                                  int sa_w, int sa_h, int cx, int cy, int sr_w, int sr_h) {
+                                  int sa_w, int sa_h, int cx, int cy, int sr_w, int sr_h, int slot = -1) {
     sa_w = (int16_t)((sa_w + 7) & ~7);
     int pad_w, pad_h, ox, oy;
     if (level == 2) { pad_w = pad_h = 63; } else { pad_w = rp.org_x - 1; pad_h = rp.org_y - 1; }
@@ -740,7 +745,7 @@ __device__ HmeGeom push_hme_level(St &st, CParams &p, int level, CPlane &rp, int
     clip_axis(org_x, ox, sa_w, pad_w, rp.width);
     sa_w = (sa_w < 8) ? sa_w : (sa_w & ~7);
     clip_axis(org_y, oy, sa_h, pad_h, rp.height);
-    push_hme_req(st, p, level, rp, org_x, org_y, bw, bh, ox, oy, sa_w, sa_h, 0);
+    push_hme_req(st, p, level, rp, org_x, org_y, bw, bh, ox, oy, sa_w, sa_h, 0, slot);
     HmeGeom g = {(int16_t)ox, (int16_t)oy};
     return g;
 }
@@ -977,123 +982,131 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         // ---- hme_level0_b64 (motion_estimation.c:1906-2036) ------------------------------------------
         // get_hme_l0_search_area reads list0/ref0's level-0 result only when both thresholds are set
         const bool l0_dep = c.enable_me_sr_adjustment && c.distance_based_hme_resizing && c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max;
+        // Levels 0 / 1 / 2 run their lane-0 style bookkeeping on 32 lanes of wave 0 instead: lane = (list, reference, region) in
+        // the reference's loop order (list, ref, h, w), so that request numbers (prefix count of the pushing lanes) match the
+        // serial order.  A lane only touches its own region's hx / hy / hs entries.
+        auto region_of = [&](int lane, int &li, int &ri, int &h, int &w) { li = lane >> 4; ri = (lane >> 2) & 3; h = (lane >> 1) & 1; w = lane & 1; };
+        auto set_region = [&](int lvl, int li, int ri, int w, int h, int x, int y, uint32_t sad) {
+            st.hx[lvl][li][ri][w][h] = (int16_t)x; st.hy[lvl][li][ri][w][h] = (int16_t)y; st.hs[lvl][li][ri][w][h] = sad;
+        };
         auto l0_pre = [&](int bi) {
             const bool dep = l0_dep;
-            if (tid == 0) {
-                st.nreq = 0;
-                const SvtHipSearchAreaMinMax base = st.hme_l0_sa;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
-                        st.l0_req[li][ri] = 0;
-                        if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 0, li, ri, 0, 0, 0); continue; }
-                        if (c.prev_me_stage_based_exit_th) {
-                            const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
-                            if (st.performed_phme[li][ri][sri] && st.prehme[li][ri][sri].sad < (c.prev_me_stage_based_exit_th >> 4)) {
-                                set_hme_all(st, p, 0, li, ri, st.prehme[li][ri][sri].col, st.prehme[li][ri][sri].row, st.prehme[li][ri][sri].sad);
-                                continue;
-                            }
+            if (tid < 64) {
+                int li, ri, h, w;
+                region_of(tid, li, ri, h, w);
+                bool push = false;
+                int  sa_w = 0, sa_h = 0;
+                const bool mine = tid < 32 && li < nl && ri < d.num_of_ref_pic_to_search[li] && !(dep && ((li == 0 && ri == 0) != (bi == 0)));
+                if (mine) {
+                    if (h == 0 && w == 0) st.l0_req[li][ri] = 0;
+                    bool handled = false;
+                    if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_region(0, li, ri, w, h, 0, 0, 0); handled = true; }
+                    if (!handled && c.prev_me_stage_based_exit_th) {
+                        const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
+                        if (st.performed_phme[li][ri][sri] && st.prehme[li][ri][sri].sad < (c.prev_me_stage_based_exit_th >> 4)) {
+                            set_region(0, li, ri, w, h, st.prehme[li][ri][sri].col, st.prehme[li][ri][sri].row, st.prehme[li][ri][sri].sad);
+                            handled = true;
                         }
-                        if (!st.do_ref[li][ri]) { set_hme_all(st, p, 0, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
-                        if (!searched(p, li)) continue;
-                        int sa_w = 0, sa_h = 0;
-                        hme_l0_search_area(st, p, li, ri, ref_distance(p, li, ri), sa_w, sa_h);
-                        st.l0_req[li][ri] = (uint8_t)(st.nreq + 1);
-                        for (int h = 0; h < c.num_hme_sa_h; h++)
-                            for (int w = 0; w < c.num_hme_sa_w; w++) {
-                                const HmeGeom g = push_hme_level(st, p, 0, p.ref[li][ri].lvl[0], (int16_t)st.org_x >> 2, (int16_t)st.org_y >> 2,
-                                                                 (int)st.b64_w >> 2, (int)st.b64_h >> 2, sa_w, sa_h, 0, 0, w, h);
-                                st.hx[0][li][ri][w][h] = g.ox; st.hy[0][li][ri][w][h] = g.oy;
-                            }
-                        if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) st.hme_l0_sa = base;
                     }
+                    if (!handled && !st.do_ref[li][ri]) { set_region(0, li, ri, w, h, 0, 0, 0xFFFFFFFFu); handled = true; }
+                    if (!handled && searched(p, li)) {
+                        hme_l0_search_area(st, p, li, ri, ref_distance(p, li, ri), sa_w, sa_h);
+                        push = true;
+                    }
+                }
+                const u64 mask = __ballot(push);
+                const int slot = __popcll(mask & ((1ull << tid) - 1ull));
+                if (push) {
+                    const HmeGeom g = push_hme_level(st, p, 0, p.ref[li][ri].lvl[0], (int16_t)st.org_x >> 2, (int16_t)st.org_y >> 2, (int)st.b64_w >> 2,
+                                                     (int)st.b64_h >> 2, sa_w, sa_h, 0, 0, w, h, slot);
+                    st.hx[0][li][ri][w][h] = g.ox; st.hy[0][li][ri][w][h] = g.oy;
+                    if (h == 0 && w == 0) st.l0_req[li][ri] = (uint8_t)(slot + 1);
+                }
+                if (tid == 0) st.nreq = __popcll(mask);
             }
         };
         auto l0_post = [&](int bi) {
             const bool dep = l0_dep;
-            if (tid == 0) {
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (dep && ((li == 0 && ri == 0) != (bi == 0))) continue;
-                        int k = st.l0_req[li][ri];
-                        if (!k) continue;
-                        k--;
-                        for (int h = 0; h < c.num_hme_sa_h; h++)
-                            for (int w = 0; w < c.num_hme_sa_w; w++, k++) {
-                                uint32_t sad; int x, y;
-                                key_to_result(st.req_key[k], full_hme, sad, x, y);
-                                st.hs[0][li][ri][w][h] = sad;
-                                st.hx[0][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[0][li][ri][w][h]) * 4);
-                                st.hy[0][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[0][li][ri][w][h]) * 4);
-                            }
-                        if (c.prehme_enable) {
-                            // get_worst_quadrant (:1872-1901): the last compare does not raise the max
-                            int ww = 0, wh = 0; uint32_t mx = 0;
-                            if (st.hs[0][li][ri][0][0] > mx) { mx = st.hs[0][li][ri][0][0]; ww = 0; wh = 0; }
-                            if (st.hs[0][li][ri][1][0] > mx) { mx = st.hs[0][li][ri][1][0]; ww = 1; wh = 0; }
-                            if (st.hs[0][li][ri][0][1] > mx) { mx = st.hs[0][li][ri][0][1]; ww = 0; wh = 1; }
-                            if (st.hs[0][li][ri][1][1] > mx) { ww = 1; wh = 1; }
-                            const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
-                            if (st.prehme[li][ri][sri].sad < st.hs[0][li][ri][ww][wh]) {
-                                st.hs[0][li][ri][ww][wh] = st.prehme[li][ri][sri].sad;
-                                st.hx[0][li][ri][ww][wh] = st.prehme[li][ri][sri].col;
-                                st.hy[0][li][ri][ww][wh] = st.prehme[li][ri][sri].row;
-                            }
-                        }
+            if (tid < 64) {
+                int li, ri, h, w;
+                region_of(tid, li, ri, h, w);
+                const bool mine = tid < 32 && li < nl && ri < d.num_of_ref_pic_to_search[li] && !(dep && ((li == 0 && ri == 0) != (bi == 0)));
+                const int  k0   = mine ? st.l0_req[li][ri] : 0;
+                if (k0) {
+                    uint32_t sad; int x, y;
+                    key_to_result(st.req_key[k0 - 1 + h * 2 + w], full_hme, sad, x, y);
+                    st.hs[0][li][ri][w][h] = sad;
+                    st.hx[0][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[0][li][ri][w][h]) * 4);
+                    st.hy[0][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[0][li][ri][w][h]) * 4);
+                }
+                // the four regions of a reference are in LDS now (one wave: the stores above precede the loads below)
+                if (k0 && h == 0 && w == 0 && c.prehme_enable) {
+                    // get_worst_quadrant (:1872-1901): the last compare does not raise the max
+                    int ww = 0, wh = 0; uint32_t mx = 0;
+                    if (st.hs[0][li][ri][0][0] > mx) { mx = st.hs[0][li][ri][0][0]; ww = 0; wh = 0; }
+                    if (st.hs[0][li][ri][1][0] > mx) { mx = st.hs[0][li][ri][1][0]; ww = 1; wh = 0; }
+                    if (st.hs[0][li][ri][0][1] > mx) { mx = st.hs[0][li][ri][0][1]; ww = 0; wh = 1; }
+                    if (st.hs[0][li][ri][1][1] > mx) { ww = 1; wh = 1; }
+                    const int sri = st.prehme[li][ri][0].sad <= st.prehme[li][ri][1].sad ? 0 : 1;
+                    if (st.prehme[li][ri][sri].sad < st.hs[0][li][ri][ww][wh]) {
+                        st.hs[0][li][ri][ww][wh] = st.prehme[li][ri][sri].sad;
+                        st.hx[0][li][ri][ww][wh] = st.prehme[li][ri][sri].col;
+                        st.hy[0][li][ri][ww][wh] = st.prehme[li][ri][sri].row;
                     }
+                }
             }
         };
         // ---- hme_level1_b64 / hme_level2_b64 (motion_estimation.c:2041-2177) ----------------------------
         auto lvl_pre = [&](int lvl) {
-            if (tid == 0) {
-                st.nreq = 0;
-                for (int i = 0; i < 2 * 4 * 2 * 2; i++) (&st.lvl_req[0][0][0][0])[i] = 0;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (!searched(p, li)) continue;
-                        if (lvl == 1) {
-                            if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_hme_all(st, p, 1, li, ri, 0, 0, 0); continue; }
-                            if (!st.do_ref[li][ri]) { set_hme_all(st, p, 1, li, ri, 0, 0, 0xFFFFFFFFu); continue; }
-                        }
-                        for (int h = 0; h < c.num_hme_sa_h; h++)
-                            for (int w = 0; w < c.num_hme_sa_w; w++) {
-                                const uint32_t exit_th = c.prev_me_stage_based_exit_th >> (lvl == 1 ? 5 : 2);
-                                if (c.prev_me_stage_based_exit_th && st.hs[lvl - 1][li][ri][w][h] < exit_th) {
-                                    st.hx[lvl][li][ri][w][h] = st.hx[lvl - 1][li][ri][w][h];
-                                    st.hy[lvl][li][ri][w][h] = st.hy[lvl - 1][li][ri][w][h];
-                                    st.hs[lvl][li][ri][w][h] = st.hs[lvl - 1][li][ri][w][h];
-                                    continue;
-                                }
-                                HmeGeom g;
-                                if (lvl == 1)
-                                    g = push_hme_level(st, p, 1, p.ref[li][ri].lvl[1], (int16_t)st.org_x >> 1, (int16_t)st.org_y >> 1, (int)st.b64_w >> 1,
-                                                       (int)st.b64_h >> 1, (int16_t)c.hme_l1_sa.width, (int16_t)c.hme_l1_sa.height,
-                                                       st.hx[0][li][ri][w][h] >> 1, st.hy[0][li][ri][w][h] >> 1, 0, 0);
-                                else
-                                    g = push_hme_level(st, p, 2, p.ref[li][ri].lvl[2], (int16_t)st.org_x, (int16_t)st.org_y, (int)st.b64_w, (int)st.b64_h,
-                                                       (int16_t)c.hme_l2_sa.width, (int16_t)c.hme_l2_sa.height, st.hx[1][li][ri][w][h],
-                                                       st.hy[1][li][ri][w][h], 0, 0);
-                                st.lvl_req[li][ri][w][h] = (uint8_t)st.nreq;
-                                st.hx[lvl][li][ri][w][h] = g.ox; st.hy[lvl][li][ri][w][h] = g.oy;
-                            }
+            if (tid < 64) {
+                int li, ri, h, w;
+                region_of(tid, li, ri, h, w);
+                bool push = false;
+                if (tid < 32) st.lvl_req[li][ri][w][h] = 0;
+                if (tid < 32 && li < nl && ri < d.num_of_ref_pic_to_search[li] && searched(p, li)) {
+                    bool live = true;
+                    if (lvl == 1) {
+                        if (c.me_early_exit_th && st.zz_sad[li][ri] < (c.me_early_exit_th >> 2)) { set_region(1, li, ri, w, h, 0, 0, 0); live = false; }
+                        else if (!st.do_ref[li][ri]) { set_region(1, li, ri, w, h, 0, 0, 0xFFFFFFFFu); live = false; }
                     }
+                    if (live) {
+                        const uint32_t exit_th = c.prev_me_stage_based_exit_th >> (lvl == 1 ? 5 : 2);
+                        if (c.prev_me_stage_based_exit_th && st.hs[lvl - 1][li][ri][w][h] < exit_th)
+                            set_region(lvl, li, ri, w, h, st.hx[lvl - 1][li][ri][w][h], st.hy[lvl - 1][li][ri][w][h], st.hs[lvl - 1][li][ri][w][h]);
+                        else push = true;
+                    }
+                }
+                const u64 mask = __ballot(push);
+                const int slot = __popcll(mask & ((1ull << tid) - 1ull));
+                if (push) {
+                    HmeGeom g;
+                    if (lvl == 1)
+                        g = push_hme_level(st, p, 1, p.ref[li][ri].lvl[1], (int16_t)st.org_x >> 1, (int16_t)st.org_y >> 1, (int)st.b64_w >> 1,
+                                           (int)st.b64_h >> 1, (int16_t)c.hme_l1_sa.width, (int16_t)c.hme_l1_sa.height,
+                                           st.hx[0][li][ri][w][h] >> 1, st.hy[0][li][ri][w][h] >> 1, 0, 0, slot);
+                    else
+                        g = push_hme_level(st, p, 2, p.ref[li][ri].lvl[2], (int16_t)st.org_x, (int16_t)st.org_y, (int)st.b64_w, (int)st.b64_h,
+                                           (int16_t)c.hme_l2_sa.width, (int16_t)c.hme_l2_sa.height, st.hx[1][li][ri][w][h],
+                                           st.hy[1][li][ri][w][h], 0, 0, slot);
+                    st.lvl_req[li][ri][w][h] = (uint8_t)(slot + 1);
+                    st.hx[lvl][li][ri][w][h] = g.ox; st.hy[lvl][li][ri][w][h] = g.oy;
+                }
+                if (tid == 0) st.nreq = __popcll(mask);
             }
         };
         auto lvl_post = [&](int lvl) {
-            if (tid == 0) {
+            if (tid < 32) {
+                int li, ri, h, w;
+                region_of(tid, li, ri, h, w);
                 const int scale = (lvl == 1) ? 2 : 1;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
-                        for (int h = 0; h < c.num_hme_sa_h; h++)
-                            for (int w = 0; w < c.num_hme_sa_w; w++) {
-                                const int k = st.lvl_req[li][ri][w][h];
-                                if (!k) continue;
-                                uint32_t sad; int x, y;
-                                key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
-                                st.hs[lvl][li][ri][w][h] = sad;
-                                st.hx[lvl][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[lvl][li][ri][w][h]) * scale);
-                                st.hy[lvl][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[lvl][li][ri][w][h]) * scale);
-                            }
+                const int k = (li < nl && ri < d.num_of_ref_pic_to_search[li]) ? st.lvl_req[li][ri][w][h] : 0;
+                if (k) {
+                    uint32_t sad; int x, y;
+                    key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
+                    st.hs[lvl][li][ri][w][h] = sad;
+                    st.hx[lvl][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[lvl][li][ri][w][h]) * scale);
+                    st.hy[lvl][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[lvl][li][ri][w][h]) * scale);
+                }
             }
         };
         // ---- set_final_seach_centre_sb (:2182-2380), hme_prune_ref_and_adjust_sr (:2477-2518) -------------
