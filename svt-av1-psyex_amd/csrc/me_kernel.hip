@@ -75,7 +75,8 @@ struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
     int16_t        pad1;
 };
 
-struct Tile { // a rectangle of a Req whose window fits the LDS arena (carries what staging / evaluation need: one LDS read)
+struct __attribute__((aligned(16))) Tile { // a rectangle of a Req whose window fits the LDS arena (carries what staging / evaluation
+                                           // need; users copy it by value: six 16-byte LDS reads instead of a read per field)
     const uint8_t *g0;     // 16-byte aligned global address of LDS byte 0 of the tile's first row
     uint32_t stride;
     uint32_t lds_off;      // byte offset in the arena
@@ -89,6 +90,18 @@ struct Tile { // a rectangle of a Req whose window fits the LDS arena (carries w
     uint32_t slices;       // narrow: block rows per position (one item each, ordered slice-major so that the lanes of a
                            // wave mostly work on different positions and rows 1 apart), else 1
     float    ng_rcp, h_rcp, vpr_rcp; // rcp_of(ng), rcp_of(h), rcp_of(pitch / 16)
+};
+
+static_assert(sizeof(Tile) % 16 == 0, "Tile is copied as 16-byte vectors");
+// register copy of a tile through whole 16-byte LDS reads (a per-field copy would issue one small LDS read per field)
+union TileRegs {
+    typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+    Tile t;
+    V4   v[sizeof(Tile) / 16];
+    __device__ __forceinline__ TileRegs(const Tile &src) {
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(Tile) / 16); k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(&src) + k); // opaque to load narrowing
+    }
 };
 
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
@@ -337,7 +350,8 @@ __device__ __forceinline__ void stage_tiles(Shared &sh) {
     const uint32_t my_vec0 = lane < ntile ? st.tile[lane].vec0 : 0xFFFFFFFFu;
     for (int i = threadIdx.x; i < ntile * kNarrowMaxPos; i += kThreads) st.sadbuf[i] = 0;
     auto locate = [&](int i, const uint8_t *&g, int &dst) { // global source and LDS destination of flattened vector i
-        const Tile &t = st.tile[tile_of((uint32_t)i, my_vec0, ntile)];
+        const TileRegs tr(st.tile[tile_of((uint32_t)i, my_vec0, ntile)]);
+        const Tile &t = tr.t;
         const int k = i - (int)t.vec0, vpr = t.pitch >> 4;
         const int row = (int)div_by_rcp((uint32_t)k, t.vpr_rcp), c = k - row * vpr;
         g   = t.g0 + (long long)row * t.stride + c * 16;
@@ -443,7 +457,8 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
     u64 cur_best = ~0ull;
     for (int it = threadIdx.x; it < nitems; it += kThreads) {
         const int   ti = tile_of((uint32_t)it, my_item0, ntile);
-        const Tile &t  = st.tile[ti];
+        const TileRegs tr(st.tile[ti]);
+        const Tile &t  = tr.t;
         uint32_t    k  = (uint32_t)it - t.item0;
         const uint32_t q = div_by_rcp(k, t.ng_rcp);
         const int   g = (int)(k - q * t.ng);
@@ -488,7 +503,8 @@ __device__ __forceinline__ void eval_keys(Shared &sh) {
     const int ntile = st.ntile;
     for (int i = threadIdx.x; i < ntile * kNarrowMaxPos; i += kThreads) {
         const int   tj = i / kNarrowMaxPos, pos = i % kNarrowMaxPos;
-        const Tile &t  = st.tile[tj];
+        const TileRegs tr(st.tile[tj]);
+        const Tile &t  = tr.t;
         u64         key = ~0ull;
         if (t.narrow && pos < t.w * t.h) {
             const int y = (int)(((float)pos + 0.5f) * __frcp_rn((float)t.w)), x = pos - y * t.w; // exact: w, pos <= 32
