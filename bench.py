@@ -234,11 +234,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
         log(f"--gpus {a.gpus} but WORLD_SIZE {world}: running with world size {world}")
+    # SVT_BENCH_REHEARSAL=1: every rank uses GPU 0 and the exchange goes through gloo on host copies -- a functional dress
+    # rehearsal of the N > 1 code path on a one-GPU box (band sharding, job lists, buffers, timing reductions); its `value`
+    # means nothing.  Never set by the driver.
+    rehearsal = os.environ.get("SVT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = api.Context(local_rank)
     ext = torch.cuda.ExternalStream(ctx.stream)
     wl = Workload(ctx, rank, world)
@@ -259,7 +268,13 @@ def main():
         done.record(ext)
         with torch.cuda.stream(comm):
             comm.wait_event(done)
-            dist.all_gather_into_tensor(gather_out, wl.me_buf)
+            if rehearsal:
+                host = wl.me_buf.cpu()
+                parts = [torch.zeros_like(host) for _ in range(world)]
+                dist.all_gather(parts, host)
+                gather_out.copy_(torch.cat(parts), non_blocking=True)
+            else:
+                dist.all_gather_into_tensor(gather_out, wl.me_buf)
 
     def run(steps, ev=None):
         with torch.cuda.stream(ext):
@@ -281,8 +296,20 @@ def main():
     run(min(a.steps, 3), ev)
     barrier()
     kms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in ev.items()}
+    if rehearsal and world > 1 and rank == 0:
+        # the gathered buffers of all ranks, unpacked, must equal a whole-picture run (picture 0 of the step)
+        pic = PICS[0]
+        whole_desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[pic]))
+        whole_desc.b64_row_start, whole_desc.b64_row_count = 0, 0
+        whole = ctx.me_picture(wl.cfgs[pic], whole_desc, wl.pics[pic[0]], wl.refs(pic), search_level=False)
+        merged = wl.layout.unpack(gather_out.cpu().numpy(), 0)
+        bad = [k for k in merged if not np.array_equal(np.asarray(whole[k]).reshape(merged[k].shape), merged[k])]
+        log("rehearsal: gathered results of picture 0 " + ("MATCH a whole-picture run" if not bad else f"DIFFER in {bad}"))
+        assert not bad, bad
     t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
+        if rehearsal:
+            t_all = t_all.cpu()
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt = float(t_all.item())
     pictures = a.steps * len(PICS)
