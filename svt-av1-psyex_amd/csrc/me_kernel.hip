@@ -137,7 +137,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     uint8_t  lvl_req[2][4][2][2];
     uint8_t  c00_req[2][4];
     // batch machinery
-    int      nreq, ntile, next_req, next_x, next_y, nitems, nvec, cur_tw, cur_th, last;
+    int      nreq, ntile, next_req, next_x, next_y, nitems, nvec, cur_tw, cur_th, last, any_narrow;
     Req      req[kMaxReq];
     u64      req_key[kMaxReq];
     Tile     tile[kMaxReq];
@@ -284,6 +284,9 @@ __device__ void plan_tiles(St &st, bool first) {
     st.nitems = (int)items;
     st.nvec   = (int)vecs;
     st.last   = st.next_req >= st.nreq;
+    int an = 0;
+    for (int i = 0; i < nt; i++) an |= st.tile[i].narrow;
+    st.any_narrow = an;
 }
 
 // wave 0: plan the next round in parallel -- lane i sizes pending request i as ONE tile; an inclusive scan of the byte
@@ -318,6 +321,7 @@ __device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
     const u64  mask  = __ballot(ok);
     const int  count = mask == ~0ull ? 64 : __builtin_ctzll(~mask); // leading requests that fit
     if (count == 0) return false;
+    const u64 nmask = __ballot(live && (st.req[live ? idx : 0].sa_w * st.req[live ? idx : 0].sa_h <= kNarrowMaxPos)); // requests evaluated by block row
     if (lane < count) {
         const Req &r = st.req[idx];
         fill_tile(st.tile[lane], r, idx, 0, 0, r.sa_w, r.sa_h, shift, pb - need, pi - items, pv - vecs);
@@ -330,6 +334,7 @@ __device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
         st.next_x   = 0;
         st.next_y   = 0;
         st.last     = idx + 1 >= nreq;
+        st.any_narrow = (nmask & ((count >= 64) ? ~0ull : ((1ull << count) - 1ull))) != 0;
     }
     return true;
 }
@@ -533,7 +538,7 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
         }
         __syncthreads();
         PROF(17);
-        const bool last = st.last; // stable until the next round's plan, which starts after this round's final barrier
+        const bool last = st.last, any_narrow = st.any_narrow; // stable until the next round's plan, which starts after this round's final barrier
         stage_tiles(sh);
         __syncthreads();
         PROF(18);
@@ -541,8 +546,10 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
         PROF(21);
         __syncthreads();
         PROF(22);
-        eval_keys(sh);
-        __syncthreads();
+        if (any_narrow) { // uniform; rounds of wide searches only have folded their keys already
+            eval_keys(sh);
+            __syncthreads();
+        }
         PROF(19);
         if (last) break;
     }
