@@ -46,8 +46,15 @@ __device__ const uint8_t c_vtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 
 __device__ const uint8_t c_htx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};
 
 __device__ __forceinline__ int32_t rshift64(i64 v, int bit) { return (int32_t)((v + ((i64)1 << (bit - 1))) >> bit); }
-__device__ __forceinline__ int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b, int bit) {
-    const i64 s = (i64)(int32_t)((uint32_t)w0 * (uint32_t)a) + (i64)(int32_t)((uint32_t)w1 * (uint32_t)b);
+// half_btf of the reference (Codec/transforms.h / inv_transforms.h): two 32-bit wrapping products, summed and rounded in
+// 64 bits.  MUL == 1 (inverse transforms): both operands of every product fit 24 signed bits -- cos weights < 2^13, data
+// < 2^19 behind the reference's own stage clamps (clamp_value to bd + 8 / 16..18 bits) -- so the full-rate v_mul_i32_i24
+// returns the same low 32 bits as the quarter-rate v_mul_lo_u32.  Forward transforms keep the 32-bit multiply: their
+// data range depends on the caller's samples.
+template <int MUL> __device__ __forceinline__ int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b, int bit) {
+    i64 s;
+    if constexpr (MUL == 1) s = (i64)__mul24(w0, a) + (i64)__mul24(w1, b);
+    else s = (i64)(int32_t)((uint32_t)w0 * (uint32_t)a) + (i64)(int32_t)((uint32_t)w1 * (uint32_t)b);
     return (int32_t)((s + ((i64)1 << (bit - 1))) >> bit);
 }
 __device__ __forceinline__ int32_t clampv(i64 v, int bit) {
@@ -66,15 +73,15 @@ __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)
 //   final stage: lane M+i with 2M-1-i, angle 64 - (2*brev(i)+1)*(32/M).
 // CLAMP < 0: forward transform (no clamps); otherwise the reference's clamp_value(stage_range) of the inverse.
 // ---------------------------------------------------------------------------------------------------------
-template <int M, int K> __device__ __forceinline__ void odd_rot(int32_t *x, const int32_t *c, int bit) {
+template <int M, int K, int MUL> __device__ __forceinline__ void odd_rot(int32_t *x, const int32_t *c, int bit) {
     constexpr int t = M >> K;
     if constexpr (K == 1) {
 #pragma unroll
         for (int j = 0; j < M / 4; j++) {
             const int p = M + M / 4 + j, m = 3 * M - 1 - p;
             const int32_t a = x[p], b = x[m];
-            x[p] = hbtf(-c[32], a, c[32], b, bit);
-            x[m] = hbtf(c[32], b, c[32], a, bit);
+            x[p] = hbtf<MUL>(-c[32], a, c[32], b, bit);
+            x[m] = hbtf<MUL>(c[32], b, c[32], a, bit);
         }
     } else {
 #pragma unroll
@@ -84,15 +91,15 @@ template <int M, int K> __device__ __forceinline__ void odd_rot(int32_t *x, cons
             for (int j = 0; j < t / 2; j++) {
                 const int p = base + t / 2 + j, m = 3 * M - 1 - p;
                 const int32_t a = x[p], b = x[m];
-                x[p] = hbtf(-c[A], a, c[B], b, bit);
-                x[m] = hbtf(c[A], b, c[B], a, bit);
+                x[p] = hbtf<MUL>(-c[A], a, c[B], b, bit);
+                x[m] = hbtf<MUL>(c[A], b, c[B], a, bit);
             }
 #pragma unroll
             for (int j = 0; j < t / 2; j++) {
                 const int p = base + t + j, m = 3 * M - 1 - p;
                 const int32_t a = x[p], b = x[m];
-                x[p] = hbtf(-c[B], a, -c[A], b, bit);
-                x[m] = hbtf(c[B], b, -c[A], a, bit);
+                x[p] = hbtf<MUL>(-c[B], a, -c[A], b, bit);
+                x[m] = hbtf<MUL>(c[B], b, -c[A], a, bit);
             }
         }
     }
@@ -113,19 +120,19 @@ template <int M, int K, int CLAMP> __device__ __forceinline__ void odd_bfly(int3
         }
     }
 }
-template <int M, bool INV> __device__ __forceinline__ void odd_final(int32_t *x, const int32_t *c, int bit) {
+template <int M, bool INV, int MUL = INV ? 1 : 0> __device__ __forceinline__ void odd_final(int32_t *x, const int32_t *c, int bit) {
 #pragma unroll
     for (int i = 0; i < M / 2; i++) {
         const int A = 64 - (2 * brevc(i, ilog2c(M)) + 1) * (32 / M), B = 64 - A, p = M + i, m = 2 * M - 1 - i;
         const int32_t a = x[p], b = x[m];
-        if constexpr (!INV) { x[p] = hbtf(c[A], a, c[B], b, bit); x[m] = hbtf(c[A], b, -c[B], a, bit); }
-        else { x[p] = hbtf(c[A], a, -c[B], b, bit); x[m] = hbtf(c[B], a, c[A], b, bit); }
+        if constexpr (!INV) { x[p] = hbtf<MUL>(c[A], a, c[B], b, bit); x[m] = hbtf<MUL>(c[A], b, -c[B], a, bit); }
+        else { x[p] = hbtf<MUL>(c[A], a, -c[B], b, bit); x[m] = hbtf<MUL>(c[B], a, c[A], b, bit); }
     }
 }
 template <int M, int K> struct OddFwd {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
         if constexpr (K < ilog2c(M)) {
-            odd_rot<M, K>(x, c, bit);
+            odd_rot<M, K, 0>(x, c, bit);
             odd_bfly<M, K, -1>(x);
             OddFwd<M, K + 1>::run(x, c, bit);
         }
@@ -135,7 +142,7 @@ template <int M, int K, int CLAMP> struct OddInv {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
         if constexpr (K >= 1) {
             odd_bfly<M, K, CLAMP>(x);
-            odd_rot<M, K>(x, c, bit);
+            odd_rot<M, K, 1>(x, c, bit);
             OddInv<M, K - 1, CLAMP>::run(x, c, bit);
         }
     }
@@ -143,25 +150,25 @@ template <int M, int K, int CLAMP> struct OddInv {
 template <int N> __device__ __forceinline__ void fdct_core(int32_t *x, const int32_t *c, int bit) {
     if constexpr (N == 2) {
         const int32_t a = x[0], b = x[1];
-        x[0] = hbtf(c[32], a, c[32], b, bit);
-        x[1] = hbtf(-c[32], b, c[32], a, bit);
+        x[0] = hbtf<0>(c[32], a, c[32], b, bit);
+        x[1] = hbtf<0>(-c[32], b, c[32], a, bit);
     } else {
         constexpr int M = N / 2;
 #pragma unroll
         for (int i = 0; i < M; i++) { const int32_t a = x[i], b = x[N - 1 - i]; x[i] = wadd(a, b); x[N - 1 - i] = wsub(a, b); }
         fdct_core<M>(x, c, bit);
         OddFwd<M, 1>::run(x, c, bit);
-        odd_final<M, false>(x, c, bit);
+        odd_final<M, false, 0>(x, c, bit);
     }
 }
 template <int N, int CLAMP> __device__ __forceinline__ void idct_core(int32_t *x, const int32_t *c, int bit) {
     if constexpr (N == 2) {
         const int32_t a = x[0], b = x[1];
-        x[0] = hbtf(c[32], a, c[32], b, bit);
-        x[1] = hbtf(c[32], a, -c[32], b, bit);
+        x[0] = hbtf<1>(c[32], a, c[32], b, bit);
+        x[1] = hbtf<1>(c[32], a, -c[32], b, bit);
     } else {
         constexpr int M = N / 2;
-        odd_final<M, true>(x, c, bit);
+        odd_final<M, true, 1>(x, c, bit);
         OddInv<M, ilog2c(M) - 1, CLAMP>::run(x, c, bit);
         idct_core<M, CLAMP>(x, c, bit);
 #pragma unroll
@@ -181,23 +188,23 @@ template <int N> __host__ __device__ constexpr int adst_perm(int k) { // P_N[2j]
     if constexpr (N == 2) return k;
     else return (k & 1) ? N - 1 - adst_perm<N / 2>(k >> 1) : adst_perm<N / 2>(k >> 1);
 }
-template <int N, int HH> __device__ __forceinline__ void adst_rot(int32_t *x, const int32_t *c, int bit) {
+template <int N, int HH, int MUL> __device__ __forceinline__ void adst_rot(int32_t *x, const int32_t *c, int bit) {
 #pragma unroll
     for (int b = 0; b < N; b += 2 * HH) {
         if constexpr (HH == 2) {
             const int32_t a = x[b + 2], d = x[b + 3];
-            x[b + 2] = hbtf(c[32], a, c[32], d, bit);
-            x[b + 3] = hbtf(c[32], a, -c[32], d, bit);
+            x[b + 2] = hbtf<MUL>(c[32], a, c[32], d, bit);
+            x[b + 3] = hbtf<MUL>(c[32], a, -c[32], d, bit);
         } else {
 #pragma unroll
             for (int j = 0; j < HH / 4; j++) {
                 const int A = (4 * j + 1) * (64 / HH), B = 64 - A, p = b + HH + 2 * j, q = b + HH + HH / 2 + 2 * j;
                 int32_t a = x[p], d = x[p + 1];
-                x[p]     = hbtf(c[A], a, c[B], d, bit);
-                x[p + 1] = hbtf(c[B], a, -c[A], d, bit);
+                x[p]     = hbtf<MUL>(c[A], a, c[B], d, bit);
+                x[p + 1] = hbtf<MUL>(c[B], a, -c[A], d, bit);
                 a = x[q]; d = x[q + 1];
-                x[q]     = hbtf(-c[B], a, c[A], d, bit);
-                x[q + 1] = hbtf(c[A], a, c[B], d, bit);
+                x[q]     = hbtf<MUL>(-c[B], a, c[A], d, bit);
+                x[q + 1] = hbtf<MUL>(c[A], a, c[B], d, bit);
             }
         }
     }
@@ -212,23 +219,23 @@ template <int N, int HH, int CLAMP> __device__ __forceinline__ void adst_bfly(in
             else { x[b + j] = clampv((i64)a + d, CLAMP); x[b + j + HH] = clampv((i64)a - d, CLAMP); }
         }
 }
-template <int N> __device__ __forceinline__ void adst_last(int32_t *x, const int32_t *c, int bit) {
+template <int N, int MUL> __device__ __forceinline__ void adst_last(int32_t *x, const int32_t *c, int bit) {
 #pragma unroll
     for (int j = 0; j < N / 2; j++) {
         const int A = (4 * j + 1) * (64 / (2 * N)), B = 64 - A;
         const int32_t a = x[2 * j], d = x[2 * j + 1];
-        x[2 * j]     = hbtf(c[A], a, c[B], d, bit);
-        x[2 * j + 1] = hbtf(c[B], a, -c[A], d, bit);
+        x[2 * j]     = hbtf<MUL>(c[A], a, c[B], d, bit);
+        x[2 * j + 1] = hbtf<MUL>(c[B], a, -c[A], d, bit);
     }
 }
 template <int N, int HH> struct AdstFwd {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
-        if constexpr (HH < N) { adst_rot<N, HH>(x, c, bit); adst_bfly<N, HH, -1>(x); AdstFwd<N, HH * 2>::run(x, c, bit); }
+        if constexpr (HH < N) { adst_rot<N, HH, 0>(x, c, bit); adst_bfly<N, HH, -1>(x); AdstFwd<N, HH * 2>::run(x, c, bit); }
     }
 };
 template <int N, int HH, int CLAMP> struct AdstInv {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
-        if constexpr (HH >= 2) { adst_bfly<N, HH, CLAMP>(x); adst_rot<N, HH>(x, c, bit); AdstInv<N, HH / 2, CLAMP>::run(x, c, bit); }
+        if constexpr (HH >= 2) { adst_bfly<N, HH, CLAMP>(x); adst_rot<N, HH, 1>(x, c, bit); AdstInv<N, HH / 2, CLAMP>::run(x, c, bit); }
     }
 };
 template <int N> __device__ __forceinline__ void fadst(int32_t *x, const int32_t *c, int bit) {
@@ -236,7 +243,7 @@ template <int N> __device__ __forceinline__ void fadst(int32_t *x, const int32_t
 #pragma unroll
     for (int k = 0; k < N; k++) { const int32_t v = x[adst_perm<N>(k)]; y[k] = (__builtin_popcount(k) & 1) ? (int32_t)(0u - (uint32_t)v) : v; }
     AdstFwd<N, 2>::run(y, c, bit);
-    adst_last<N>(y, c, bit);
+    adst_last<N, 0>(y, c, bit);
 #pragma unroll
     for (int j = 0; j < N / 2; j++) { x[2 * j] = y[2 * j + 1]; x[2 * j + 1] = y[N - 2 - 2 * j]; }
 }
@@ -244,7 +251,7 @@ template <int N, int CLAMP> __device__ __forceinline__ void iadst(int32_t *x, co
     int32_t y[N];
 #pragma unroll
     for (int j = 0; j < N / 2; j++) { y[2 * j + 1] = x[2 * j]; y[N - 2 - 2 * j] = x[2 * j + 1]; }
-    adst_last<N>(y, c, bit);
+    adst_last<N, 1>(y, c, bit);
     AdstInv<N, N / 2, CLAMP>::run(y, c, bit);
 #pragma unroll
     for (int k = 0; k < N; k++) x[adst_perm<N>(k)] = (__builtin_popcount(k) & 1) ? (int32_t)(0u - (uint32_t)y[k]) : y[k];
