@@ -46,6 +46,10 @@ constexpr int kWaves    = kThreads / 64;
 constexpr int kMaxReq   = 32;    // searches per batch (4 HME regions x 8 refs)
 constexpr int kWinBytes = SVT_HIP_ME_WIN_BYTES; // LDS window arena
 constexpr int kSrc64Pitch = 80, kSrc32Pitch = 48, kSrc16Pitch = 16; // LDS row pitches of the source views: block rows 2 apart land on different banks
+#ifndef SVT_ME_ROWS_PER_SLICE
+#define SVT_ME_ROWS_PER_SLICE 2
+#endif
+constexpr int kRowsPerSlice = SVT_ME_ROWS_PER_SLICE; // block rows one item of a row-split (narrow) search accumulates before its LDS atomics
 constexpr int kNarrowMaxPos = 32; // searches with at most this many positions are split by block row instead
 
 // z_to_raster, motion_estimation.c:2520-2531: n_idx (quad-tree order) -> raster-within-depth PU index
@@ -235,7 +239,7 @@ __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, in
     t.pitch     = (uint16_t)row_pitch(shift, w, r.bw);
     t.shift     = (uint16_t)shift;
     t.ng        = (uint32_t)((shift & 3) + w + 3) >> 2;
-    t.slices    = narrow ? r.bh : 1u;
+    t.slices    = narrow ? (uint32_t)(r.bh + kRowsPerSlice - 1) / kRowsPerSlice : 1u;
     t.item0     = item0;
     t.nitems    = t.ng * (uint32_t)h * t.slices;
     t.vec0      = vec0;
@@ -307,7 +311,7 @@ __device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
         const uint32_t rows  = (uint32_t)(r.sa_h - 1 + (r.bh - 1) * r.rs + 1);
         const uint32_t ng    = (uint32_t)((shift & 3) + r.sa_w + 3) >> 2;
         need  = pitch * rows + 16u;
-        items = ng * (uint32_t)r.sa_h * ((r.sa_w * r.sa_h <= kNarrowMaxPos) ? r.bh : 1u);
+        items = ng * (uint32_t)r.sa_h * ((r.sa_w * r.sa_h <= kNarrowMaxPos) ? (uint32_t)(r.bh + kRowsPerSlice - 1) / kRowsPerSlice : 1u);
         vecs  = (pitch >> 4) * rows;
     }
     uint32_t pb = need, pi = items, pv = vecs; // inclusive scans: lane j's terms reach the lanes above it
@@ -478,7 +482,7 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
         const int      sp    = (t.level == 2) ? kSrc64Pitch : (t.level == 1 ? kSrc32Pitch : kSrc16Pitch);
         uint32_t       s4[4];
         if (t.narrow) {
-            quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice, slice + 1, s4);
+            quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, (int)t.bh), s4);
             for (int i = 0; i < 4; i++) {
                 const int x = xq + i;
                 if (x >= 0 && x < t.w) atomicAdd(&st.sadbuf[ti * kNarrowMaxPos + y * t.w + x], s4[i]);
