@@ -528,19 +528,25 @@ __device__ __forceinline__ void eval_keys(Shared &sh) {
     }
 }
 
+// wave 0: plan the next round of the pending requests (first: also reset the requests' keys)
+__device__ __forceinline__ void plan_round(St &st, bool first) {
+    if (first && (int)threadIdx.x < st.nreq) st.req_key[threadIdx.x] = (0xffffffull << 32) | 0xffffffffull;
+    const bool planned = plan_tiles_wave(st, first); // the serial planner only handles requests that must be cut into tiles
+    if (!planned && threadIdx.x == 0) plan_tiles(st, first);
+}
+
 // all threads: run st.req[0 .. nreq) (nreq >= 1) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x),
-// or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.  The caller's barrier has published
-// the requests; on return every thread may read the keys.
+// or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.  The FIRST round has been planned by
+// wave 0 right behind its pushes (plan_round(st, true)) and published by the caller's barrier; on return every thread may
+// read the keys.
 __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
     St &st = sh.st;
     for (bool first = true;; first = false) {
         PROF(23);
-        if (threadIdx.x < 64) { // wave 0 plans; the serial planner only handles requests that must be cut into tiles
-            if (first && (int)threadIdx.x < st.nreq) st.req_key[threadIdx.x] = (0xffffffull << 32) | 0xffffffffull;
-            const bool planned = plan_tiles_wave(st, first);
-            if (!planned && threadIdx.x == 0) plan_tiles(st, first);
+        if (!first) {
+            if (threadIdx.x < 64) plan_round(st, false);
+            __syncthreads();
         }
-        __syncthreads();
         PROF(17);
         const bool last = st.last, any_narrow = st.any_narrow; // stable until the next round's plan, which starts after this round's final barrier
         stage_tiles(sh);
@@ -1308,6 +1314,9 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             default: main_pre(); break;
             }
             if (run) {
+                // wave 0 has just pushed the stage's searches: it plans their first round right away (same wave: its LDS writes
+                // are in order), so that one barrier publishes requests and plan together
+                if (step < kProbe && tid < 64 && st.nreq) plan_round(st, true);
                 __syncthreads();
                 PROF(step == kMain ? 20 : 6 + step);
                 if (step == kC00 && bi == 0 && st.tf_exit) { step = kEnd; continue; } // uniform: LDS value read after the barrier
