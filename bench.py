@@ -182,7 +182,7 @@ def cpu_baseline(wl, seconds_target=12.0):
             pyoracle.me_picture(me_impl, cfg, desc, wl.host8[CUR], refs8, search_level=False)
             for ts in RD_SIZES:
                 jobs = row_jobs[(row, ts)]
-                rd.run_oracle(dict(bit_depth=10, quant_kind=0, tx_size=ts, src_stride=W, pred_stride=W), src10, pred10, jobs, qrows, want_coeffs=False,
+                pyoracle.rd_batch(dict(bit_depth=10, quant_kind=0, tx_size=ts, src_stride=W, pred_stride=W), src10, pred10, jobs, qrows, want_coeffs=False,
                               want_recon=False, impl=rd_impl)
         return work
 

@@ -97,3 +97,63 @@ def config_from_preset_ref(preset_desc):
     rc = load_ref().ref_me_config_from_preset(C.byref(preset_desc), C.byref(cfg))
     assert rc == 0
     return cfg
+
+
+# ---- CPU mirrors of the batched device entries (same descriptors, host pointers): checkers for tests / smoke / bench baseline ----
+def rd_batch(desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_recon=True, qmatrix=None, iqmatrix=None, impl="oracle"):
+    """CPU mirror of svt_hip_rd_batch on host numpy arrays (test infrastructure; imports oracle/).  impl: "oracle" = the C
+    restatement (oracle/rd_oracle.c); "ref" / "ref_simd" = the reference's own `_c` / AVX2+SSE4.1 kernels chained by
+    oracle/ref_harness.c:ref_rd_batch (build container, or wherever oracle/_ref/libsvtref.so travelled to)."""
+    if impl == "oracle":
+        fn = load_oracle().orc_rd_batch
+    else:
+        r = load_ref()
+        r.ref_set_simd_rd(1 if impl == "ref_simd" else 0)
+        fn = r.ref_rd_batch
+    ts = desc_fields["tx_size"]
+    npk = min(abi.TX_W[ts], 32) * min(abi.TX_H[ts], 32)
+    n = len(jobs)
+    out = {name: np.zeros((n, k), dtype=dt) for name, dt, k in abi.RD_OUT_FIELDS}
+    if want_coeffs:
+        for name in ("coeff", "qcoeff", "dqcoeff"):
+            out[name] = np.zeros((n, npk), np.int32)
+    recon = pred.copy() if want_recon else None
+    d = abi.RdBatchDesc(n_jobs=n, src=src.ctypes.data, pred=pred.ctypes.data, recon=recon.ctypes.data if want_recon else None,
+                        jobs=jobs.ctypes.data, quant_rows=quant_rows.ctypes.data, n_quant_rows=len(quant_rows), **desc_fields)
+    for name in out:
+        setattr(d, name, out[name].ctypes.data)
+    if qmatrix is not None:
+        qmatrix, iqmatrix = np.ascontiguousarray(qmatrix, np.uint8), np.ascontiguousarray(iqmatrix, np.uint8)
+        d.qmatrix, d.iqmatrix = qmatrix.ctypes.data, iqmatrix.ctypes.data
+    assert fn(C.byref(d)) == 0
+    if want_recon:
+        out["recon"] = recon
+    return out
+
+
+
+def block_stats(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
+    """src / ref: 2-D numpy planes (uint8 or uint16); returns a dict of per-job arrays from oracle/stats_oracle.c.
+    psy_rd: also return the psy-RD terms (jobs must then have widths / heights that are multiples of 4)."""
+    n = len(jobs)
+    out = {name: np.zeros(n, dtype=dt) for name, dt in abi.STATS_OUT_FIELDS}
+    d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
+    if psy_rd is not None:
+        d.psy_rd = psy_rd
+        for name, dt in abi.PSY_OUT_FIELDS:
+            out[name] = np.zeros(n, dtype=dt)
+            setattr(d, name, out[name].ctypes.data)
+    src, ref, jobs = np.ascontiguousarray(src), np.ascontiguousarray(ref), np.ascontiguousarray(jobs)
+    d.src, d.ref, d.jobs = src.ctypes.data, ref.ctypes.data, jobs.ctypes.data
+    for name, _ in abi.STATS_OUT_FIELDS:
+        if name == "satd" and not satd:
+            continue
+        setattr(d, name, out[name].ctypes.data)
+    oracle.orc_block_stats_batch.restype = C.c_int
+    rc = oracle.orc_block_stats_batch(C.byref(d))
+    assert rc == 0, rc
+    if not satd:
+        out.pop("satd")
+    return out
+
+

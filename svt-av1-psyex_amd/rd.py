@@ -38,38 +38,6 @@ def grid_jobs(width, height, stride, tx_size, tx_type=0, quant_row=0, org=0):
     return jobs
 
 
-def run_oracle(desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_recon=True, qmatrix=None, iqmatrix=None, impl="oracle"):
-    """CPU mirror of svt_hip_rd_batch on host numpy arrays (test infrastructure; imports oracle/).  impl: "oracle" = the C
-    restatement (oracle/rd_oracle.c); "ref" / "ref_simd" = the reference's own `_c` / AVX2+SSE4.1 kernels chained by
-    oracle/ref_harness.c:ref_rd_batch (build container, or wherever oracle/_ref/libsvtref.so travelled to)."""
-    import pyoracle
-    if impl == "oracle":
-        fn = pyoracle.load_oracle().orc_rd_batch
-    else:
-        r = pyoracle.load_ref()
-        r.ref_set_simd_rd(1 if impl == "ref_simd" else 0)
-        fn = r.ref_rd_batch
-    ts = desc_fields["tx_size"]
-    npk = min(abi.TX_W[ts], 32) * min(abi.TX_H[ts], 32)
-    n = len(jobs)
-    out = {name: np.zeros((n, k), dtype=dt) for name, dt, k in abi.RD_OUT_FIELDS}
-    if want_coeffs:
-        for name in ("coeff", "qcoeff", "dqcoeff"):
-            out[name] = np.zeros((n, npk), np.int32)
-    recon = pred.copy() if want_recon else None
-    d = abi.RdBatchDesc(n_jobs=n, src=src.ctypes.data, pred=pred.ctypes.data, recon=recon.ctypes.data if want_recon else None,
-                        jobs=jobs.ctypes.data, quant_rows=quant_rows.ctypes.data, n_quant_rows=len(quant_rows), **desc_fields)
-    for name in out:
-        setattr(d, name, out[name].ctypes.data)
-    if qmatrix is not None:
-        qmatrix, iqmatrix = np.ascontiguousarray(qmatrix, np.uint8), np.ascontiguousarray(iqmatrix, np.uint8)
-        d.qmatrix, d.iqmatrix = qmatrix.ctypes.data, iqmatrix.ctypes.data
-    assert fn(C.byref(d)) == 0
-    if want_recon:
-        out["recon"] = recon
-    return out
-
-
 def run_hip(ctx, desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_recon=True, qmatrix=None, iqmatrix=None):
     """Runs svt_hip_rd_batch on device copies of the inputs; returns numpy results."""
     import torch

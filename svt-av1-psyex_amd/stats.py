@@ -1,4 +1,4 @@
-"""Host-side helpers of the batched block-statistics entry (svt_hip_block_stats_batch) and its oracle counterpart."""
+"""Host-side helpers of the batched block-statistics entry (svt_hip_block_stats_batch)."""
 import ctypes as C
 
 import numpy as np
@@ -22,31 +22,6 @@ def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False, subpel=
         jobs["subpel_x"] = rng.integers(0, 8, n)
         jobs["subpel_y"] = rng.integers(0, 8, n)
     return jobs
-
-
-def run_oracle(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
-    """src / ref: 2-D numpy planes (uint8 or uint16); returns a dict of per-job arrays from oracle/stats_oracle.c.
-    psy_rd: also return the psy-RD terms (jobs must then have widths / heights that are multiples of 4)."""
-    n = len(jobs)
-    out = {name: np.zeros(n, dtype=dt) for name, dt in abi.STATS_OUT_FIELDS}
-    d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
-    if psy_rd is not None:
-        d.psy_rd = psy_rd
-        for name, dt in abi.PSY_OUT_FIELDS:
-            out[name] = np.zeros(n, dtype=dt)
-            setattr(d, name, out[name].ctypes.data)
-    src, ref, jobs = np.ascontiguousarray(src), np.ascontiguousarray(ref), np.ascontiguousarray(jobs)
-    d.src, d.ref, d.jobs = src.ctypes.data, ref.ctypes.data, jobs.ctypes.data
-    for name, _ in abi.STATS_OUT_FIELDS:
-        if name == "satd" and not satd:
-            continue
-        setattr(d, name, out[name].ctypes.data)
-    oracle.orc_block_stats_batch.restype = C.c_int
-    rc = oracle.orc_block_stats_batch(C.byref(d))
-    assert rc == 0, rc
-    if not satd:
-        out.pop("satd")
-    return out
 
 
 def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None):

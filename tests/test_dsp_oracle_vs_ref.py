@@ -4,6 +4,7 @@ hadamard_test.cc, VarianceTest.cc, quantize_func_test.cc / QuantAsmTest.cc, FwdT
 import ctypes as C
 
 import numpy as np
+import pyoracle
 import pytest
 
 from txfm_cases import TX_H, TX_W, ref_fwd, ref_inv, residual_block, valid_types
@@ -251,7 +252,7 @@ def test_rd_chain_oracle_equals_reference_chain(ref, oracle, ts, impl):
             jobs["tx_type"] = rng.choice(types, len(jobs))
             jobs["quant_row"] = rng.integers(0, 3, len(jobs))
             f = dict(bit_depth=bd, quant_kind=0, tx_size=ts, src_stride=192, pred_stride=192)
-            a = rd.run_oracle(f, src, pred, jobs, rows)
-            b = rd.run_oracle(f, src, pred, jobs, rows, impl=impl)
+            a = pyoracle.rd_batch(f, src, pred, jobs, rows)
+            b = pyoracle.rd_batch(f, src, pred, jobs, rows, impl=impl)
             for k in a:
                 assert np.array_equal(a[k], b[k]), (ts, bd, pattern, k, np.argwhere(a[k] != b[k])[:3].tolist())

@@ -1,6 +1,7 @@
 """GPU: svt_hip_rd_batch (residual -> fwd txfm -> quant -> dist -> inv txfm -> SSE) against the oracle chain,
 for all 19 transform sizes x the transform types AV1 allows per size, 8- and 10-bit, both quantizers."""
 import numpy as np
+import pyoracle
 import pytest
 
 from svt_av1_psyex_amd import abi, rd
@@ -45,7 +46,7 @@ def test_rd_batch_matches_oracle(hip_ctx, tx_size):
                 jobs["quant_row"] = rng.integers(0, 3, len(jobs))
                 jobs["pred_offset"] = jobs["src_offset"][rng.permutation(len(jobs))]  # pred block elsewhere than src block
                 f = dict(bit_depth=bd, quant_kind=quant_kind, tx_size=tx_size, src_stride=192, pred_stride=192)
-                want = rd.run_oracle(f, src, pred, jobs, rows)
+                want = pyoracle.rd_batch(f, src, pred, jobs, rows)
                 got = rd.run_hip(hip_ctx, f, src, pred, jobs, rows)
                 _check(want, got, (tx_size, bd, pattern, quant_kind))
 
@@ -59,7 +60,7 @@ def test_every_transform_type_individually(hip_ctx):
         for tt in valid_types(ts):
             jobs = rd.grid_jobs(192, 128, 192, ts, tx_type=tt)[:6]
             f = dict(bit_depth=10, quant_kind=0, tx_size=ts, src_stride=192, pred_stride=192)
-            _check(rd.run_oracle(f, src, pred, jobs, rows), rd.run_hip(hip_ctx, f, src, pred, jobs, rows), (ts, tt))
+            _check(pyoracle.rd_batch(f, src, pred, jobs, rows), rd.run_hip(hip_ctx, f, src, pred, jobs, rows), (ts, tt))
 
 
 def test_rd_batch_rejects_bad_descriptors(hip_ctx):
@@ -88,7 +89,7 @@ def test_partial_frequency_shapes_and_quantization_matrices(hip_ctx, tx_size):
                 qm = rng.integers(16, 256, npk).astype(np.uint8) if use_qm else None   # AV1 matrices: 32 = unit weight
                 iqm = rng.integers(16, 256, npk).astype(np.uint8) if use_qm else None
                 f = dict(bit_depth=bd, quant_kind=quant_kind, tx_size=tx_size, src_stride=192, pred_stride=192)
-                want = rd.run_oracle(f, src, pred, jobs, rows, qmatrix=qm, iqmatrix=iqm)
+                want = pyoracle.rd_batch(f, src, pred, jobs, rows, qmatrix=qm, iqmatrix=iqm)
                 got = rd.run_hip(hip_ctx, f, src, pred, jobs, rows, qmatrix=qm, iqmatrix=iqm)
                 _check(want, got, (tx_size, bd, quant_kind, use_qm))
 
@@ -105,4 +106,4 @@ def test_out_of_range_16bit_samples_stay_exact(hip_ctx, tx_size):
     jobs = rd.grid_jobs(192, 128, 192, tx_size)
     jobs["tx_type"] = rng.choice(valid_types(tx_size), len(jobs))
     f = dict(bit_depth=10, quant_kind=0, tx_size=tx_size, src_stride=192, pred_stride=192)
-    _check(rd.run_oracle(f, src, pred, jobs, rows), rd.run_hip(hip_ctx, f, src, pred, jobs, rows), tx_size)
+    _check(pyoracle.rd_batch(f, src, pred, jobs, rows), rd.run_hip(hip_ctx, f, src, pred, jobs, rows), tx_size)

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pyoracle
 import pytest
 
 from stats_cases import PSY_RD, load_fixture, load_subpel_fixture, mismatches
@@ -35,13 +36,13 @@ def test_batch_matches_oracle_on_random_jobs(hip_ctx, oracle, bd):
     jobs = stats.random_jobs(rng, W, H, 3000)
     odd = stats.random_jobs(rng, W, H, 64, sizes=[(12, 20), (1, 1), (3, 128), (128, 5), (24, 24), (100, 7)])  # not AV1 shapes: still defined
     jobs = np.concatenate([jobs, odd])
-    a = stats.run_oracle(oracle, src, ref, jobs, bd, satd=(bd == 8))
+    a = pyoracle.block_stats(oracle, src, ref, jobs, bd, satd=(bd == 8))
     b = stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=(bd == 8))
     assert not [m for m in mismatches(a, b, bd) if "psy" not in m]
     # psy-RD terms: AV1 shapes only (multiples of 4), three strengths incl. 0
     for psy_rd in (0.0, 0.5, 4.0):
         jp = jobs[:1500]
-        a = stats.run_oracle(oracle, src, ref, jp, bd, satd=False, psy_rd=psy_rd)
+        a = pyoracle.block_stats(oracle, src, ref, jp, bd, satd=False, psy_rd=psy_rd)
         b = stats.run_hip(hip_ctx, src, ref, jp, bd, satd=False, psy_rd=psy_rd)
         assert not [m for m in mismatches(a, b, bd) if "satd" not in m], psy_rd
 
@@ -164,7 +165,7 @@ def test_sub_pixel_variance_fixture_and_oracle(hip_ctx, oracle):
         dt = np.uint8 if bd == 8 else np.uint16
         s = rng.integers(0, 1 << bd, (H, W)).astype(dt); r = rng.integers(0, 1 << bd, (H, W)).astype(dt)
         jb = stats.random_jobs(rng, W, H, 1200, subpel=True)
-        a = stats.run_oracle(oracle, s, r, jb, bd, satd=(bd == 8), psy_rd=1.0)
+        a = pyoracle.block_stats(oracle, s, r, jb, bd, satd=(bd == 8), psy_rd=1.0)
         b = stats.run_hip(hip_ctx, s, r, jb, bd, satd=(bd == 8), psy_rd=1.0)
         assert not mismatches(a, b, bd), bd
 
