@@ -453,6 +453,8 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     int32_t *co_out = (p.d.coeff && valid) ? p.d.coeff + (size_t)job * NP : nullptr;
     int32_t *q_out  = (p.d.qcoeff && valid) ? p.d.qcoeff + (size_t)job * NP : nullptr;
     int32_t *dq_out = (p.d.dqcoeff && valid) ? p.d.dqcoeff + (size_t)job * NP : nullptr;
+    const int32_t zb_c[2]  = {log_scale ? ((q.zbin[0] + (1 << (log_scale - 1))) >> log_scale) : q.zbin[0], log_scale ? ((q.zbin[1] + (1 << (log_scale - 1))) >> log_scale) : q.zbin[1]};
+    const int32_t rnd_c[2] = {log_scale ? ((q.round[0] + (1 << (log_scale - 1))) >> log_scale) : q.round[0], log_scale ? ((q.round[1] + (1 << (log_scale - 1))) >> log_scale) : q.round[1]};
     for (int rc = l; rc < NP; rc += LW) {
         const int r = rc / WP, c = rc - r * WP, ac = rc != 0;
         const bool kept = pf == 0 || (c < keep_w && r < keep_h);
@@ -460,7 +462,19 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         satd += (uint32_t)a;
         int32_t qv = 0, dq = 0;
         const int32_t wt = qm ? qm[rc] : 32, iwt = qm ? iqm[rc] : 32; // AOM_QM_BITS = 5
-        if (p.d.quant_kind == 0) { // svt_aom_quantize_b_c_ii / svt_aom_highbd_quantize_b_c (full_loop.c:29-79,149-198)
+        if (p.d.quant_kind == 0 && !qm) { // the same "b" quantizer with the flat matrix (wt = iwt = 32), in 32-bit arithmetic:
+            // |coeff| < 2^24 for any int16 residual (forward gain <= N per pass, minus the stage shifts), so (|coeff| + round) << 5
+            // and its products' high parts fit 32 bits; every intermediate equals the reference's 64-bit value
+            const int32_t zb = zb_c[ac];
+            if (a >= zb) {
+                int32_t t = a + rnd_c[ac];
+                if (BD == 8) t = t > 32767 ? 32767 : t;
+                const int32_t tw  = t << 5;
+                const int32_t tmp = (int32_t)(((i64)tw * q.quant[ac]) >> 16) + tw;
+                qv = (int32_t)(((i64)tmp * q.quant_shift[ac]) >> (16 - log_scale + 5));
+                dq = (qv * (int32_t)q.dequant[ac]) >> log_scale;
+            }
+        } else if (p.d.quant_kind == 0) { // svt_aom_quantize_b_c_ii / svt_aom_highbd_quantize_b_c (full_loop.c:29-79,149-198)
             const int32_t zb = log_scale ? ((q.zbin[ac] + (1 << (log_scale - 1))) >> log_scale) : q.zbin[ac];
             if ((i64)a * wt >= ((i64)zb << 5)) {
                 i64 t = (i64)a + (log_scale ? ((q.round[ac] + (1 << (log_scale - 1))) >> log_scale) : q.round[ac]);
