@@ -392,9 +392,15 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     const int bit_col = c_fwd_cos_col[ilog2c(W) - 2][ilog2c(H) - 2], bit_row = c_fwd_cos_row[ilog2c(W) - 2][ilog2c(H) - 2];
 
     // residual (svt_residual_kernel8bit / 16bit): int16 arithmetic as in the reference
-    for (int i = l; i < W * H; i += LW) {
-        const int r = i / W, c = i - r * W;
-        A[r * PA + c] = (int16_t)((int16_t)src[(size_t)r * p.d.src_stride + c] - (int16_t)pred[(size_t)r * p.d.pred_stride + c]);
+    // runs of RUN samples per (unaligned) vector load: the planes' offsets and strides are the caller's
+    constexpr int RUN = W < 8 ? W : 8, RPR = W / RUN; // run length, runs per row
+    typedef Pix __attribute__((ext_vector_type(RUN), aligned(sizeof(Pix)))) RunU;
+    for (int i = l; i < RPR * H; i += LW) {
+        const int r = i / RPR, c = (i - r * RPR) * RUN;
+        const RunU sv = *reinterpret_cast<const RunU *>(src + (size_t)r * p.d.src_stride + c);
+        const RunU pv = *reinterpret_cast<const RunU *>(pred + (size_t)r * p.d.pred_stride + c);
+#pragma unroll
+        for (int k = 0; k < RUN; k++) A[r * PA + c + k] = (int16_t)((int16_t)sv[k] - (int16_t)pv[k]);
     }
     __syncthreads();
     // forward columns (av1_tranform_two_d_core_c, transforms.c:2287-2308)
@@ -540,15 +546,28 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         for (int r = 0; r < H; r++) x[r] = (r < HP) ? clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16) : 0; // rows >= 32 of a 64-row block are exactly zero after the row pass: constants, so the network prunes itself
         inv_1d<H, COL_CLAMP>(x, vt);
         shift_vec<H>(x, -4);
-        Pix *rec = (p.d.recon && valid) ? static_cast<Pix *>(p.d.recon) + jb.pred_offset : nullptr;
+        // residual (with the vertical flip undone) back to LDS, row-major: the reconstruction below moves whole runs
 #pragma unroll
-        for (int r = 0; r < H; r++) {
-            const int res = x[ud ? H - 1 - r : r];
-            int v = (int)pred[(size_t)r * p.d.pred_stride + l] + res;
-            v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
-            if (rec) rec[(size_t)r * p.d.pred_stride + l] = (Pix)v;
-            const i64 e = (i64)src[(size_t)r * p.d.src_stride + l] - v;
-            sse += (u64)(e * e);
+        for (int r = 0; r < H; r++) A[r * PA + l] = x[ud ? H - 1 - r : r];
+    }
+    __syncthreads();
+    {
+        Pix *rec = (p.d.recon && valid) ? static_cast<Pix *>(p.d.recon) + jb.pred_offset : nullptr;
+        for (int i = l; i < RPR * H; i += LW) {
+            const int r = i / RPR, c = (i - r * RPR) * RUN;
+            const RunU pv = *reinterpret_cast<const RunU *>(pred + (size_t)r * p.d.pred_stride + c);
+            const RunU sv = *reinterpret_cast<const RunU *>(src + (size_t)r * p.d.src_stride + c);
+            RunU out;
+#pragma unroll
+            for (int k = 0; k < RUN; k++) {
+                int v = (int)pv[k] + A[r * PA + c + k];
+                v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
+                out[k] = (Pix)v;
+                const int e = (int)sv[k] - v;
+                const uint32_t ue = (uint32_t)(e < 0 ? -e : e);
+                sse += (u64)(ue * ue); // |e| < 2^16: the square fits 32 bits
+            }
+            if (rec) *reinterpret_cast<RunU *>(rec + (size_t)r * p.d.pred_stride + c) = out;
         }
     }
     sse = seg_sum_u64<LW>(sse);
