@@ -372,12 +372,16 @@ __device__ __forceinline__ void stage_tiles(Shared &sh) {
         const uint8_t *g0, *g1, *g2, *g3;
         int            d0, d1, d2, d3;
         locate(i0, g0, d0); locate(i1, g1, d1); locate(i2, g2, d2); locate(i3, g3, d3);
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(g0), v1 = *reinterpret_cast<const uint4 *>(g1);
-        const uint4 v2 = *reinterpret_cast<const uint4 *>(g2), v3 = *reinterpret_cast<const uint4 *>(g3);
-        *reinterpret_cast<uint4 *>(&sh.win[d0]) = v0;
-        *reinterpret_cast<uint4 *>(&sh.win[d1]) = v1;
-        *reinterpret_cast<uint4 *>(&sh.win[d2]) = v2;
-        *reinterpret_cast<uint4 *>(&sh.win[d3]) = v3;
+        // the plane addresses come out of LDS-resident structs, which hides their address space from the compiler: say "global"
+        // (a flat load also counts against the LDS wait counter)
+        typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) V4 GV4;
+        const V4 v0 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g0)), v1 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g1));
+        const V4 v2 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g2)), v3 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g3));
+        *reinterpret_cast<V4 *>(&sh.win[d0]) = v0;
+        *reinterpret_cast<V4 *>(&sh.win[d1]) = v1;
+        *reinterpret_cast<V4 *>(&sh.win[d2]) = v2;
+        *reinterpret_cast<V4 *>(&sh.win[d3]) = v3;
     }
 }
 
@@ -659,8 +663,9 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                 __syncthreads(); // previous tile fully consumed
                 for (int i = threadIdx.x; i < vec_per_row * rows; i += kThreads) {
                     const int row = i / vec_per_row, c = i - row * vec_per_row;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(gwin - shift + (long long)row * m.stride + c * 16);
-                    *reinterpret_cast<uint4 *>(&sh.win[row * pitch + c * 16]) = v;
+                    typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+                    const V4 v = *reinterpret_cast<const __attribute__((address_space(1))) V4 *>(reinterpret_cast<uintptr_t>(gwin - shift + (long long)row * m.stride + c * 16)); // global, not flat
+                    *reinterpret_cast<V4 *>(&sh.win[row * pitch + c * 16]) = v;
                 }
                 __syncthreads();
                 const int ng = ((shift & 3) + w + 3) >> 2;
