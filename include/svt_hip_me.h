@@ -210,6 +210,30 @@ typedef struct SvtHipMeJob {
 } SvtHipMeJob;
 int svt_hip_me_pictures_async(SvtHipContext *ctx, uint32_t n_pictures, const SvtHipMeJob *jobs);
 
+/* ---- dynamic-GOP detector HME (me_type ME_DG_DETECTOR: me_process.c:113-118,326-331) ---- */
+/* The fields of DGDetectorMetrics (pcs.h:731-737) that dg_detector_hme_level0 accumulates (pd_process.c:541-581). */
+typedef struct SvtHipDgMetrics {
+    uint64_t tot_dist;       /* sum of the level-0 SADs */
+    uint32_t tot_cplx;       /* blocks with SAD > 16*16*30 */
+    uint32_t tot_active;     /* blocks with a non-zero vector */
+    int32_t  sum_in_vectors; /* inward (+) / outward (-) vector components */
+    uint32_t reserved;
+} SvtHipDgMetrics;
+
+/* One call = dg_detector_hme_level0(ppcs, seg_idx) for EVERY segment of the picture (pd_process.c:492-588):
+ * per b64, a full-SAD svt_sad_loop_kernel search of the 16x16 block of `src`'s sixteenth plane in `ref`'s
+ * sixteenth plane (early_hme_b64, pd_process.c:393-490; search area 16 / 64 / 128 squared by input_resolution),
+ * then the four metric sums.  `metrics` is a HOST pointer; `b64_sad` ([n_b64], hme_level0_sad) and `b64_mv`
+ * ([n_b64][2] = sr_center col,row in full-resolution pixels) are optional HOST pointers to the per-block
+ * results the reference only keeps in locals.  Complete on return. */
+int svt_hip_dg_detector_hme_level0(SvtHipContext *ctx, const SvtHipPaPicture *src, const SvtHipPaPicture *ref,
+                                   uint16_t aligned_width, uint16_t aligned_height, uint8_t input_resolution,
+                                   SvtHipDgMetrics *metrics, uint32_t *b64_sad, int16_t *b64_mv);
+/* Asynchronous form: all three are DEVICE pointers (b64_sad / b64_mv may be NULL); enqueued on the context stream. */
+int svt_hip_dg_detector_hme_level0_async(SvtHipContext *ctx, const SvtHipPaPicture *src, const SvtHipPaPicture *ref,
+                                         uint16_t aligned_width, uint16_t aligned_height, uint8_t input_resolution,
+                                         SvtHipDgMetrics *metrics_dev, uint32_t *b64_sad_dev, int16_t *b64_mv_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,7 +181,21 @@ def gen_block_stats():
     print("wrote block_stats")
 
 
-GENERATORS = {"me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats}
+def gen_dg_detector():
+    """Metrics of the reference's dg_detector_hme_level0 (2 x 2 segments) on tests/dg_cases.py's grid."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dg_cases import GRID, METRICS, DgCase
+    rows = []
+    for w, h, kind in GRID:
+        c = DgCase(w, h, kind)
+        m = pyoracle.dg_detector("ref", c.src, c.ref, *c.args(), segments=(2, 2))
+        rows.append([m[k] for k in METRICS])
+    np.savez_compressed(os.path.join(OUT, "dg_detector.npz"), width=np.array([g[0] for g in GRID]), height=np.array([g[1] for g in GRID]),
+                        kind=np.array([g[2] for g in GRID]), metrics=np.array(rows, np.int64))
+    print("dg_detector.npz", rows)
+
+
+GENERATORS = {"me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats, "dg": gen_dg_detector}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

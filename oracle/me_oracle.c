@@ -1103,6 +1103,7 @@ size_t orc_sizeof(int what) {
     case 2: return sizeof(SvtHipPlaneDesc);
     case 3: return sizeof(SvtHipMeResults);
     case 4: return sizeof(SvtHipMePresetDesc);
+    case 5: return sizeof(SvtHipDgMetrics);
     default: return 0;
     }
 }

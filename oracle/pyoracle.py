@@ -92,6 +92,24 @@ def me_picture(which, cfg, desc, cur, refs, search_level=True):
     return arrs
 
 
+def dg_detector(which, src, ref, aligned_width, aligned_height, input_resolution, segments=(1, 1)):
+    """dg_detector_hme_level0 on HostPyramids.  which: 'oracle' (metrics + per-b64 SAD / vector) or 'ref' (metrics only,
+    run segment by segment over a segments = (columns, rows) split as the reference's ME threads do)."""
+    m = abi.DgMetrics()
+    s16, r16 = src.desc(0), ref.desc(0)
+    if which == "ref":
+        rc = load_ref().ref_dg_detector(C.byref(s16), C.byref(r16), aligned_width, aligned_height, input_resolution, segments[0],
+                                        segments[1], C.byref(m))
+        assert rc == 0 and m.reserved == segments[0] * segments[1]  # seg_completed
+        return m.as_dict()
+    n = ((aligned_width + 63) // 64) * ((aligned_height + 63) // 64)
+    sad, mv = np.zeros(n, np.uint32), np.zeros((n, 2), np.int16)
+    rc = load_oracle().orc_dg_detector_hme_level0(C.byref(s16), C.byref(r16), aligned_width, aligned_height, input_resolution, C.byref(m),
+                                                  sad.ctypes.data_as(C.c_void_p), mv.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return dict(m.as_dict(), b64_sad=sad, b64_mv=mv)
+
+
 def config_from_preset_ref(preset_desc):
     cfg = abi.MeConfig()
     rc = load_ref().ref_me_config_from_preset(C.byref(preset_desc), C.byref(cfg))

@@ -325,6 +325,49 @@ int ref_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
     return 0;
 }
 
+/* dg_detector_hme_level0 (pd_process.c:492-588) run for every segment of a seg_cols x seg_rows split, exactly as
+ * svt_aom_motion_estimation_kernel does for ME_DG_DETECTOR tasks (me_process.c:326-331).  Returns the metrics. */
+#include "svt_threads.h"
+#include "reference_object.h"
+void dg_detector_hme_level0(struct PictureParentControlSet *ppcs, uint32_t seg_idx);
+
+int ref_dg_detector(const SvtHipPlaneDesc *src16, const SvtHipPlaneDesc *ref16, uint16_t aligned_width, uint16_t aligned_height,
+                    uint8_t input_resolution, uint32_t seg_cols, uint32_t seg_rows, SvtHipDgMetrics *out) {
+    ref_set_simd(g_simd);
+    SequenceControlSet      *scs = calloc(1, sizeof(*scs));
+    PictureParentControlSet *pcs = calloc(1, sizeof(*pcs)), *rpcs = calloc(1, sizeof(*rpcs));
+    EbObjectWrapper          wrap[2];
+    EbPaReferenceObject      pa[2];
+    DGDetectorSeg            dg;
+    memset(wrap, 0, sizeof(wrap)); memset(pa, 0, sizeof(pa)); memset(&dg, 0, sizeof(dg));
+    EbPictureBufferDesc *s = make_desc(src16), *r = make_desc(ref16);
+    pa[0].sixteenth_downsampled_picture_ptr = s;
+    pa[1].sixteenth_downsampled_picture_ptr = r;
+    wrap[0].object_ptr = &pa[0];
+    wrap[1].object_ptr = &pa[1];
+    scs->b64_size = 64;
+    pcs->scs = scs; rpcs->scs = scs;
+    pcs->pa_ref_pic_wrapper  = &wrap[0];
+    rpcs->pa_ref_pic_wrapper = &wrap[1];
+    pcs->input_resolution = (EbInputResolution)input_resolution;
+    pcs->aligned_width    = aligned_width;
+    pcs->aligned_height   = aligned_height;
+    pcs->me_segments_column_count = (uint8_t)seg_cols;
+    pcs->me_segments_row_count    = (uint8_t)seg_rows;
+    pcs->me_segments_total_count  = (uint16_t)(seg_cols * seg_rows);
+    pcs->dg_detector = &dg;
+    dg.ref_pic       = rpcs;
+    dg.metrics_mutex  = svt_create_mutex();
+    dg.frame_done_sem = svt_create_semaphore(0, 1);
+    for (uint32_t seg = 0; seg < seg_cols * seg_rows; seg++) dg_detector_hme_level0(pcs, seg);
+    out->tot_dist = dg.metrics.tot_dist; out->tot_cplx = dg.metrics.tot_cplx; out->tot_active = dg.metrics.tot_active;
+    out->sum_in_vectors = dg.metrics.sum_in_vectors; out->reserved = dg.metrics.seg_completed;
+    svt_destroy_mutex(dg.metrics_mutex);
+    svt_destroy_semaphore(dg.frame_done_sem);
+    free(s); free(r); free(pcs); free(rpcs); free(scs);
+    return 0;
+}
+
 size_t ref_sizeof_me_context(void) { return sizeof(MeContext); }
 
 /* ---- accessors for static / header-only data of the reference ---- */

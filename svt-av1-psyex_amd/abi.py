@@ -94,6 +94,15 @@ class MeResults(C.Structure):
     ]
 
 
+class DgMetrics(C.Structure):
+    """SvtHipDgMetrics (include/svt_hip_me.h)."""
+    _fields_ = [("tot_dist", C.c_uint64), ("tot_cplx", C.c_uint32), ("tot_active", C.c_uint32), ("sum_in_vectors", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {"tot_dist": self.tot_dist, "tot_cplx": self.tot_cplx, "tot_active": self.tot_active, "sum_in_vectors": self.sum_in_vectors}
+
+
 class MeJob(C.Structure):
     _fields_ = [("cfg", C.c_void_p), ("desc", C.c_void_p), ("cur", C.c_void_p), ("refs", (C.c_void_p * 4) * 2), ("results", C.c_void_p)]
 

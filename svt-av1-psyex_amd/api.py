@@ -168,6 +168,30 @@ class Context:
         self.check(lib().svt_hip_me_pictures_async(self._h, len(jobs), arr), "svt_hip_me_pictures_async")
 
 
+    def dg_detector_hme_level0(self, src, ref, aligned_width, aligned_height, input_resolution, per_block=True):
+        """dg_detector_hme_level0 over the whole picture (pd_process.c:492-588): metrics dict, plus the per-b64
+        SAD [n_b64] and vector [n_b64, 2] (col, row) when per_block."""
+        n = ((aligned_width + 63) // 64) * ((aligned_height + 63) // 64)
+        m = abi.DgMetrics()
+        sad = np.zeros(n, np.uint32) if per_block else None
+        mv = np.zeros((n, 2), np.int16) if per_block else None
+        rc = lib().svt_hip_dg_detector_hme_level0(self._h, src._h, ref._h, aligned_width, aligned_height, input_resolution, C.byref(m),
+                                                  sad.ctypes.data_as(C.c_void_p) if per_block else None,
+                                                  mv.ctypes.data_as(C.c_void_p) if per_block else None)
+        self.check(rc, "svt_hip_dg_detector_hme_level0")
+        out = m.as_dict()
+        if per_block:
+            out["b64_sad"], out["b64_mv"] = sad, mv
+        return out
+
+
+    def dg_detector_hme_level0_async(self, src, ref, aligned_width, aligned_height, input_resolution, metrics_ptr, sad_ptr=None, mv_ptr=None):
+        """Asynchronous form on DEVICE pointers (ints); enqueues on the context stream."""
+        rc = lib().svt_hip_dg_detector_hme_level0_async(self._h, src._h, ref._h, aligned_width, aligned_height, input_resolution,
+                                                        C.c_void_p(metrics_ptr), C.c_void_p(sad_ptr), C.c_void_p(mv_ptr))
+        self.check(rc, "svt_hip_dg_detector_hme_level0_async")
+
+
 class DevicePicture:
     def __init__(self, ctx, handle, picture_number):
         self.ctx, self._h, self.picture_number = ctx, handle, picture_number

@@ -169,6 +169,7 @@ size_t svt_hip_sizeof(int what) {
     case 2: return sizeof(SvtHipPlaneDesc);
     case 3: return sizeof(SvtHipMeResults);
     case 4: return sizeof(SvtHipMePresetDesc);
+    case 5: return sizeof(SvtHipDgMetrics);
     default: return 0;
     }
 }

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_compiled_layout(oracle):
     L = api.lib()
-    for i, t in enumerate([abi.MeConfig, abi.MePictureDesc, abi.PlaneDesc, abi.MeResults, abi.MePresetDesc]):
+    for i, t in enumerate([abi.MeConfig, abi.MePictureDesc, abi.PlaneDesc, abi.MeResults, abi.MePresetDesc, abi.DgMetrics]):
         assert C.sizeof(t) == L.svt_hip_sizeof(i) == oracle.orc_sizeof(i), t.__name__
 
 

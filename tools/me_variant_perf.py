@@ -17,7 +17,7 @@ for dist in (1,2,8):
     nb=((w+63)//64)*((h+63)//64); n=abi.n_pu(c.desc.enable_me_16x16,c.desc.enable_me_8x8)
     res=abi.MeResults(); keep=[]
     for name,dt,cnt in abi.RESULT_FIELDS:
-        if name in ('hme_sc','hme_sad','do_ref'): continue
+        if name in ('hme_sc','hme_sad','do_ref') or (os.environ.get('NO_SB_BEST') and name.startswith('sb_best')): continue
         t_=torch.zeros(nb*cnt(n,c.desc.max_refs,c.desc.max_cand)*np.dtype(dt).itemsize,dtype=torch.uint8,device='cuda'); keep.append(t_); setattr(res,name,t_.data_ptr())
     torch.cuda.synchronize()
     with torch.cuda.stream(ext):
