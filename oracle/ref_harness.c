@@ -515,3 +515,46 @@ int ref_rd_batch(const SvtHipRdBatchDesc *d) {
     free(res); free(co); free(q); free(dq); free(p16); free(r16);
     return 0;
 }
+
+/* =====================================================================================================================
+ * The kernel chain of the TPL dispenser's inter / recon evaluation (Codec/src_ops_process.c:857-872 and get_quantize_error
+ * :225-249) through the reference's own functions: svt_aom_subtract_block on every (1 << sub)-th row -> svt_av1_wht_fwd_txfm
+ * (DCT_DCT, partial-frequency shape) -> svt_aom_satd -> svt_av1_quantize_fp with the DCT_DCT scan -> svt_av1_block_error.
+ * 16-pixel blocks (dispenser_search_level 0): tx_size TX_16X16 / TX_16X8 / TX_16X4 for subsample_tx 0 / 1 / 2 (:380-382,531).
+ * coeff is deliberately left dirty between blocks, as the dispenser's stack buffer is.
+ * out8 = {inter_cost (satd << sub), eob, recon_error, sse}
+ * ===================================================================================================================== */
+void svt_av1_wht_fwd_txfm(int16_t *src_diff, int bw, int32_t *coeff, TxSize tx_size, EB_TRANS_COEFF_SHAPE pf_shape, int bit_depth, int is_hbd);
+
+int ref_tpl_chain(const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride, int sub, int pf_shape,
+                  const SvtHipQuantRow *qr, int32_t *coeff, int32_t *qcoeff, int32_t *dqcoeff, int64_t *out4) {
+    static const TxSize sizes[3] = {TX_16X16, TX_16X8, TX_16X4};
+    const TxSize tx_size = sizes[sub];
+    const int    size    = 16;
+    svt_aom_subtract_block = svt_aom_subtract_block_c;
+    svt_aom_satd           = svt_aom_satd_c;
+    svt_av1_quantize_fp    = svt_av1_quantize_fp_c;
+    svt_av1_block_error    = svt_av1_block_error_c;
+    svt_av1_fwd_txfm2d_16x16 = svt_av1_transform_two_d_16x16_c; svt_av1_fwd_txfm2d_16x8 = svt_av1_fwd_txfm2d_16x8_c; svt_av1_fwd_txfm2d_16x4 = svt_av1_fwd_txfm2d_16x4_c;
+    svt_av1_fwd_txfm2d_16x16_N2 = svt_aom_transform_two_d_16x16_N2_c; svt_av1_fwd_txfm2d_16x8_N2 = svt_av1_fwd_txfm2d_16x8_N2_c; svt_av1_fwd_txfm2d_16x4_N2 = svt_av1_fwd_txfm2d_16x4_N2_c;
+    svt_av1_fwd_txfm2d_16x16_N4 = svt_aom_transform_two_d_16x16_N4_c; svt_av1_fwd_txfm2d_16x8_N4 = svt_av1_fwd_txfm2d_16x8_N4_c; svt_av1_fwd_txfm2d_16x4_N4 = svt_av1_fwd_txfm2d_16x4_N4_c;
+    DECLARE_ALIGNED(16, int16_t, src_diff[16 * 16]);
+    DECLARE_ALIGNED(16, int16_t, zbin[8]); DECLARE_ALIGNED(16, int16_t, rnd[8]); DECLARE_ALIGNED(16, int16_t, qnt[8]);
+    DECLARE_ALIGNED(16, int16_t, qsh[8]); DECLARE_ALIGNED(16, int16_t, deq[8]);
+    for (int k = 0; k < 8; k++) { zbin[k] = qr->zbin[k != 0]; rnd[k] = qr->round_fp[k != 0]; qnt[k] = qr->quant_fp[k != 0]; qsh[k] = qr->quant_shift[k != 0]; deq[k] = qr->dequant[k != 0]; }
+    svt_aom_subtract_block(size >> sub, size, src_diff, size << sub, src, (ptrdiff_t)src_stride << sub, pred, (ptrdiff_t)pred_stride << sub);
+    svt_av1_wht_fwd_txfm(src_diff, size << sub, coeff, tx_size, (EB_TRANS_COEFF_SHAPE)pf_shape, 8, 0);
+    out4[0] = (int64_t)svt_aom_satd(coeff, (size * size) >> sub) << sub;
+    /* get_quantize_error */
+    const ScanOrder *const so      = &av1_scan_orders[tx_size][DCT_DCT];
+    const int              pix_num = 1 << num_pels_log2_lookup[txsize_to_bsize[tx_size]];
+    const int              shift   = tx_size == TX_32X32 ? 0 : 2;
+    uint16_t               eob     = 0;
+    svt_av1_quantize_fp(coeff, pix_num, zbin, rnd, qnt, qsh, qcoeff, dqcoeff, deq, &eob, so->scan, so->iscan);
+    int64_t sse, err = svt_av1_block_error(coeff, dqcoeff, pix_num, &sse) >> shift;
+    out4[1] = eob;
+    out4[2] = err > 1 ? err : 1;
+    sse >>= shift;
+    out4[3] = sse > 1 ? sse : 1;
+    return 0;
+}
