@@ -93,7 +93,9 @@ typedef struct SvtHipBlockJob {
 
 typedef struct SvtHipBlockStatsDesc {
     uint8_t  bit_depth;   /* 8: planes are uint8; 10: planes are uint16 */
-    uint8_t  reserved[3];
+    uint8_t  temporal_layer_index; /* pcs->temporal_layer_index (0..5), read for facade_dist only */
+    uint8_t  spy_rd;               /* EbSvtAv1EncConfiguration.spy_rd (API/EbSvtAv1Enc.h:1020), read for facade_dist only */
+    uint8_t  reserved;
     uint32_t n_jobs;
     uint32_t src_stride, ref_stride; /* in samples */
     const void           *src, *ref; /* device pointers */
@@ -108,7 +110,18 @@ typedef struct SvtHipBlockStatsDesc {
     double    psy_rd;     /* strength; only used for psy_dist */
     uint64_t *psy_energy; /* svt_psy_distortion / svt_psy_distortion_hbd */
     uint64_t *psy_dist;   /* get_svt_psy_full_dist: (uint64_t)(psy_energy * psy_rd), one fp64 multiply */
+    /* PSYEX distortion facades (C_DEFAULT/picture_operators_c.c:85-174), src = input, ref = prediction or reconstruction */
+    uint64_t      *psy_sse;       /* svt_spatial_psy_distortion_kernel_c: sse + (uint64_t)(psy_energy * psy_rd) when psy_rd > 0 */
+    const uint8_t *pred_mode;     /* [n_jobs] PredictionMode of the candidate, device pointer; mandatory with facade_dist */
+    const uint8_t *compound_type; /* [n_jobs] CompoundType, device pointer; mandatory with facade_dist */
+    uint64_t      *facade_dist;   /* svt_spatial_full_distortion_kernel_facade: the SSE with the spy-rd mode biases */
 } SvtHipBlockStatsDesc;
+
+/* The integer biases svt_spatial_full_distortion_kernel_facade applies to an SSE (picture_operators_c.c:130-171): host-only
+ * arithmetic, for callers that already hold the SSE (e.g. SvtHipRdBatchDesc.sse).  mode / compound_type are the reference's
+ * PredictionMode / CompoundType enumerators; temporal_layer_index <= 5. */
+uint64_t svt_hip_spy_rd_bias(uint64_t sse, uint32_t area_width, uint32_t area_height, uint8_t mode, uint8_t compound_type,
+                             uint8_t temporal_layer_index, double psy_rd, uint8_t spy_rd);
 
 /* Enqueues one batch on the context stream (asynchronous); one wave per job. */
 int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d);

@@ -14,6 +14,7 @@
 #define SVT_HIP_LEAF_H
 
 #include <stddef.h>
+#include <stdbool.h>
 #include <stdint.h>
 #include "svt_hip_me.h"
 
@@ -57,6 +58,15 @@ uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_o
                                                 uint32_t recon_stride, uint32_t area_width, uint32_t area_height);
 uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
                                                uint32_t recon_stride, uint32_t area_width, uint32_t area_height);
+
+/* PSYEX facades (common_dsp_rtcd.h:165-166; bodies C_DEFAULT/picture_operators_c.c:85-174).  PredictionMode and CompoundType are
+ * ATTRIBUTE_PACKED (one byte) enums in the reference (definitions.h:1126,1197): uint8_t here is the same ABI. */
+uint64_t svt_spatial_psy_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
+                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height, double psy_rd);
+uint64_t svt_spatial_full_distortion_kernel_facade_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon,
+                                                       int32_t recon_offset, uint32_t recon_stride, uint32_t area_width, uint32_t area_height,
+                                                       bool hbd_md, uint8_t mode, uint8_t compound_type, uint8_t temporal_layer_index,
+                                                       double psy_rd, uint8_t spy_rd);
 
 /* svt_aom_hadamard_NxN (common_dsp_rtcd.h:1075-1085), svt_aom_satd (aom_dsp_rtcd.h:209) */
 void svt_aom_hadamard_4x4_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);

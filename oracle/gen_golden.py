@@ -112,6 +112,10 @@ def gen_presets():
 PSY_RD = 1.35  # strength used for the psy_dist column of the block-statistics fixture
 
 
+# svt_spatial_full_distortion_kernel_facade fixture columns: name -> (temporal_layer_index, spy_rd, psy_rd)
+FACADE_SETTINGS = {"facade_a": (3, 1, PSY_RD), "facade_b": (5, 1, 0.0), "facade_c": (0, 1, 0.0), "facade_d": (4, 2, 0.0)}
+
+
 def gen_block_stats():
     """Block statistics (SAD / SSE / variance / hadamard_path SATD) of the reference's `_c` kernels on two small planes."""
     from svt_av1_psyex_amd import abi, stats
@@ -159,8 +163,31 @@ def gen_block_stats():
                 exp["sse"][j] = ref.svt_full_distortion_kernel16_bits_c(ptr(s), C.c_uint32(0), C.c_uint32(W), ptr(r), C.c_int32(0), C.c_uint32(W), C.c_uint32(w), C.c_uint32(h))
                 exp["variance"][j] = ref.svt_aom_variance_highbd_c(ptr(s), W, ptr(r), W, w, h, C.byref(vs)) & 0xFFFFFFFF
                 exp["var_sse"][j] = vs.value
+        # PSYEX facades (picture_operators_c.c:85-174).  svt_spatial_psy_distortion_kernel_c exists for 8-bit input only: the 10-bit
+        # psy_sse column is the sum of the two reference results it would add (sse + get_svt_psy_full_dist).
+        ref.ref_set_simd_rd(0)  # the facade dispatches through svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits
+        ref.svt_spatial_psy_distortion_kernel_c.restype = ref.svt_spatial_full_distortion_kernel_facade.restype = C.c_uint64
+        frng = np.random.default_rng(500 + bd)
+        modes, comps = frng.integers(0, 25, len(jobs)).astype(np.uint8), frng.integers(0, 4, len(jobs)).astype(np.uint8)
+        modes[:13] = np.arange(13)  # every intra mode at least once
+        fac = {k: np.zeros(len(jobs), np.uint64) for k in FACADE_SETTINGS}
+        for j, jb in enumerate(jobs):
+            w, h = int(jb["width"]), int(jb["height"])
+            s = src.reshape(-1)[int(jb["src_offset"]):]
+            r = refp.reshape(-1)[int(jb["ref_offset"]):]
+            if bd == 8:
+                exp["psy_sse"][j] = ref.svt_spatial_psy_distortion_kernel_c(ptr(s), C.c_uint32(0), C.c_uint32(W), ptr(r), C.c_int32(0), C.c_uint32(W), C.c_uint32(w),
+                                                                            C.c_uint32(h), C.c_double(PSY_RD))
+            else:
+                exp["psy_sse"][j] = exp["sse"][j] + exp["psy_dist"][j]
+            for k, (tli, spy, prd) in FACADE_SETTINGS.items():
+                fac[k][j] = ref.svt_spatial_full_distortion_kernel_facade(ptr(s), C.c_uint32(0), C.c_uint32(W), ptr(r), C.c_int32(0), C.c_uint32(W), C.c_uint32(w),
+                                                                          C.c_uint32(h), C.c_bool(bd != 8), C.c_uint8(int(modes[j])), C.c_uint8(int(comps[j])),
+                                                                          C.c_uint8(tli), C.c_double(prd), C.c_uint8(spy))
         out.update({f"src{bd}": src, f"ref{bd}": refp, f"jobs{bd}": jobs.view(np.uint8).reshape(len(jobs), -1)})
         out.update({f"{k}{bd}": v for k, v in exp.items()})
+        out.update({f"fac_mode{bd}": modes, f"fac_comp{bd}": comps})
+        out.update({f"{k}{bd}": v for k, v in fac.items()})
     # sub-pixel variance (8-bit planes of above): AV1 variance shapes x all 64 phases, from svt_aom_sub_pixel_variance{W}x{H}_c
     rng = np.random.default_rng(208)
     src, refp = out["src8"], out["ref8"]

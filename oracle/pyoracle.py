@@ -150,7 +150,7 @@ def rd_batch(desc_fields, src, pred, jobs, quant_rows, want_coeffs=True, want_re
 
 
 
-def block_stats(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
+def block_stats(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None, facade=None):
     """src / ref: 2-D numpy planes (uint8 or uint16); returns a dict of per-job arrays from oracle/stats_oracle.c.
     psy_rd: also return the psy-RD terms (jobs must then have widths / heights that are multiples of 4)."""
     n = len(jobs)
@@ -161,6 +161,11 @@ def block_stats(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
         for name, dt in abi.PSY_OUT_FIELDS:
             out[name] = np.zeros(n, dtype=dt)
             setattr(d, name, out[name].ctypes.data)
+    if facade:  # dict(pred_mode, compound_type, temporal_layer_index, spy_rd): svt_spatial_full_distortion_kernel_facade
+        modes, comps = np.ascontiguousarray(facade["pred_mode"], np.uint8), np.ascontiguousarray(facade["compound_type"], np.uint8)
+        out["facade_dist"] = np.zeros(n, np.uint64)
+        d.pred_mode, d.compound_type, d.facade_dist = modes.ctypes.data, comps.ctypes.data, out["facade_dist"].ctypes.data
+        d.temporal_layer_index, d.spy_rd = facade["temporal_layer_index"], facade["spy_rd"]
     src, ref, jobs = np.ascontiguousarray(src), np.ascontiguousarray(ref), np.ascontiguousarray(jobs)
     d.src, d.ref, d.jobs = src.ctypes.data, ref.ctypes.data, jobs.ctypes.data
     for name, _ in abi.STATS_OUT_FIELDS:

@@ -161,6 +161,30 @@ uint32_t orc_sub_pixel_variance8(const uint8_t *a, int a_stride, int xoffset, in
     return v;
 }
 
+/* svt_spatial_full_distortion_kernel_facade's spy-rd biases (C_DEFAULT/picture_operators_c.c:130-171) on an SSE already computed.
+ * Enumerators: PredictionMode Codec/definitions.h:1126-1162 (DC 0, V 1, H 2, SMOOTH 9..11, PAETH 12, first inter 13, compound
+ * 17..24), CompoundType :1197-1202 (AVERAGE 0, DISTWTD 1, WEDGE 2, DIFFWTD 3). */
+int64_t orc_spy_rd_facade(int64_t dist, uint32_t w, uint32_t h, uint8_t mode, uint8_t comp, uint8_t tli, double psy_rd, uint8_t spy_rd) {
+    static const uint8_t intra_weights[6] = {8, 8, 9, 10, 11, 12};
+    const int blurry_intra = mode == 0 || (mode >= 9 && mode <= 11), neutral_intra = mode == 1 || mode == 2 || mode == 12;
+    const int is_intra = mode < 13, is_compound = mode >= 17 && mode < 25;
+    if (spy_rd != 1) return dist;
+    if (blurry_intra) {
+        if (psy_rd == 0.0) dist = dist * 5 / 4;
+    } else if (neutral_intra)
+        dist = dist * 9 / 8;
+    else if (is_compound) {
+        if (comp == 0 || comp == 1) dist = dist * 5 / 4;
+        else if (comp == 3) dist = dist * 9 / 8;
+    }
+    if (is_intra) {
+        if (tli >= 2) dist = dist * intra_weights[tli] / 8;
+        if (w == 64 && h == 64) dist = dist * 3 / 2;
+        else if (w * h <= 32 * 32) dist = dist * 17 / 16;
+    }
+    return dist;
+}
+
 int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
     if (!d || (d->bit_depth != 8 && d->bit_depth != 10) || !d->src || !d->ref || !d->jobs) return 2;
     if (d->satd && d->bit_depth != 8) return 2;
@@ -203,6 +227,22 @@ int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
                                                   (const uint8_t *)d->ref + (size_t)jb.ref_offset * bpp, d->ref_stride, (uint32_t)w, (uint32_t)h, d->bit_depth != 8);
             if (d->psy_energy) d->psy_energy[j] = e;
             if (d->psy_dist) d->psy_dist[j] = (uint64_t)((double)e * d->psy_rd); /* get_svt_psy_full_dist, psy_rd.c:277-293 */
+        }
+        if (d->psy_sse) { /* svt_spatial_psy_distortion_kernel_c, picture_operators_c.c:85-112 */
+            uint64_t psy = 0;
+            if (d->psy_rd > 0.0) {
+                if ((w & 3) || (h & 3)) return 2;
+                const size_t bpp = d->bit_depth == 8 ? 1 : 2;
+                const void *ps = subpel ? (d->bit_depth == 8 ? (const void *)f8 : (const void *)f16) : (const void *)((const uint8_t *)d->src + (size_t)jb.src_offset * bpp);
+                psy = (uint64_t)((double)orc_psy_distortion(ps, s_stride, (const uint8_t *)d->ref + (size_t)jb.ref_offset * bpp, d->ref_stride, (uint32_t)w,
+                                                            (uint32_t)h, d->bit_depth != 8) * d->psy_rd);
+            }
+            d->psy_sse[j] = sse + psy;
+        }
+        if (d->facade_dist) {
+            if (!d->pred_mode || !d->compound_type || d->temporal_layer_index > 5) return 2;
+            d->facade_dist[j] = (uint64_t)orc_spy_rd_facade((int64_t)sse, (uint32_t)w, (uint32_t)h, d->pred_mode[j], d->compound_type[j],
+                                                            d->temporal_layer_index, d->psy_rd, d->spy_rd);
         }
         if (d->sad) d->sad[j] = sad;
         if (d->sse) d->sse[j] = sse;

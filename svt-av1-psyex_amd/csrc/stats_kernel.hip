@@ -22,6 +22,7 @@
 #include <string.h>
 #include <mutex>
 #include "svt_hip_internal.h"
+#include "../../include/svt_hip_spy_rd.h"
 #include "../../include/svt_hip_dsp.h"
 #include "../../include/svt_hip_leaf.h"
 
@@ -279,6 +280,10 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         if (p.d.sse) p.d.sse[job] = sse;
         if (p.d.var_sse) p.d.var_sse[job] = sq32;
         if (p.d.variance) p.d.variance[job] = sq32 - (uint32_t)(((i64)sum * sum) / (w * h));
+        // svt_spatial_full_distortion_kernel_facade (picture_operators_c.c:115-174)
+        if (p.d.facade_dist)
+            p.d.facade_dist[job] = (u64)svt_hip_spy_rd_bias_inline((i64)sse, (uint32_t)w, (uint32_t)h, p.d.pred_mode[job], p.d.compound_type[job],
+                                                                   p.d.temporal_layer_index, p.d.psy_rd, p.d.spy_rd);
     }
     if (p.d.satd) { // hadamard_path_c: square blocks, <= 32x32 tiles
         uint32_t satd = 0;
@@ -299,7 +304,7 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         satd = wave_sum(satd);
         if (lane == 0) p.d.satd[job] = satd;
     }
-    if (p.d.psy_energy || p.d.psy_dist) { // svt_psy_distortion{,_hbd}: one lane per 8x8 (or 4x4) tile
+    if (p.d.psy_energy || p.d.psy_dist || (p.d.psy_sse && p.d.psy_rd > 0.0)) { // svt_psy_distortion{,_hbd}: one lane per 8x8 (or 4x4) tile
         const int n = (w >= 8 && h >= 8) ? 8 : 4, ntx = (w + n - 1) / n, nt = ntx * ((h + n - 1) / n); // the reference's loops: i < height; i += n
         u64 total = 0;
         for (int t = lane; t < nt; t += 64) {
@@ -313,8 +318,9 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         if (lane == 0) {
             if (p.d.psy_energy) p.d.psy_energy[job] = e;
             if (p.d.psy_dist) p.d.psy_dist[job] = (u64)((double)e * p.d.psy_rd); // get_svt_psy_full_dist, psy_rd.c:277-293
+            if (p.d.psy_sse) p.d.psy_sse[job] = sse + (u64)((double)e * p.d.psy_rd); // svt_spatial_psy_distortion_kernel_c, picture_operators_c.c:85-112
         }
-    }
+    } else if (p.d.psy_sse && lane == 0) p.d.psy_sse[job] = sse; // psy_rd <= 0: the plain SSE
 }
 
 // ---- svt_sad_loop_kernel: one thread per search position, first minimum in raster order through a 64-bit key ------
@@ -407,6 +413,8 @@ int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d)
     if (d->bit_depth != 8 && d->bit_depth != 10) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "bit_depth %u", d->bit_depth);
     if (!d->src || !d->ref || !d->jobs) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the block-stats batch is null");
     if (d->satd && d->bit_depth != 8) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "hadamard_path works on 8-bit input (enc_mode_config.c:2186)");
+    if (d->facade_dist && (!d->pred_mode || !d->compound_type || d->temporal_layer_index > 5))
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "facade_dist needs pred_mode, compound_type and temporal_layer_index <= 5 (got %u)", d->temporal_layer_index);
     hipSetDevice(ctx->device);
     StatsParams p;
     p.d = *d;
@@ -585,6 +593,26 @@ uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_of
                                                uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
     return leaf_stats(reinterpret_cast<uint16_t *>(input) + input_offset, input_stride, reinterpret_cast<uint16_t *>(recon) + recon_offset, recon_stride,
                       (int)area_width, (int)area_height, 10, false).sse;
+}
+
+uint64_t svt_hip_spy_rd_bias(uint64_t sse, uint32_t area_width, uint32_t area_height, uint8_t mode, uint8_t compound_type, uint8_t temporal_layer_index,
+                             double psy_rd, uint8_t spy_rd) {
+    return (uint64_t)svt_hip_spy_rd_bias_inline((int64_t)sse, area_width, area_height, mode, compound_type, temporal_layer_index, psy_rd, spy_rd);
+}
+
+uint64_t svt_spatial_full_distortion_kernel_facade_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
+                                                       uint32_t recon_stride, uint32_t area_width, uint32_t area_height, bool hbd_md, uint8_t mode,
+                                                       uint8_t compound_type, uint8_t temporal_layer_index, double psy_rd, uint8_t spy_rd) {
+    const uint64_t sse = hbd_md ? svt_full_distortion_kernel16_bits_hip(input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height)
+                                : svt_spatial_full_distortion_kernel_hip(input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height);
+    return svt_hip_spy_rd_bias(sse, area_width, area_height, mode, compound_type, temporal_layer_index, psy_rd, spy_rd);
+}
+
+uint64_t svt_spatial_psy_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
+                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height, double psy_rd) {
+    const StatsOut o = leaf_stats(input + input_offset, input_stride, recon + recon_offset, recon_stride, (int)area_width, (int)area_height, 8, false,
+                                  psy_rd > 0.0, psy_rd);
+    return o.sse + (psy_rd > 0.0 ? o.psy_dist : 0);
 }
 
 uint64_t svt_psy_distortion_hip(const uint8_t *input, uint32_t input_stride, const uint8_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height) {

@@ -24,20 +24,25 @@ def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False, subpel=
     return jobs
 
 
-def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
+def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None, facade=None):
+    """facade: dict(pred_mode=u8[n], compound_type=u8[n], temporal_layer_index=int, spy_rd=int) -> also `facade_dist`."""
     import torch
     from . import api
     L = api.lib()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
     n = len(jobs)
     t_src, t_ref, t_jobs = dev(src), dev(ref), dev(jobs)
-    fields = list(abi.STATS_OUT_FIELDS) + (list(abi.PSY_OUT_FIELDS) if psy_rd is not None else [])
+    fields = list(abi.STATS_OUT_FIELDS) + (list(abi.PSY_OUT_FIELDS) if psy_rd is not None else []) + (list(abi.FACADE_OUT_FIELDS) if facade else [])
     outs = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in fields}
     d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
     if psy_rd is not None:
         d.psy_rd = psy_rd
         for name, _ in abi.PSY_OUT_FIELDS:
             setattr(d, name, outs[name].data_ptr())
+    if facade:
+        t_mode, t_comp = dev(np.asarray(facade["pred_mode"], np.uint8)), dev(np.asarray(facade["compound_type"], np.uint8))
+        d.pred_mode, d.compound_type, d.facade_dist = t_mode.data_ptr(), t_comp.data_ptr(), outs["facade_dist"].data_ptr()
+        d.temporal_layer_index, d.spy_rd = facade["temporal_layer_index"], facade["spy_rd"]
     d.src, d.ref, d.jobs = t_src.data_ptr(), t_ref.data_ptr(), t_jobs.data_ptr()
     for name, _ in abi.STATS_OUT_FIELDS:
         if name == "satd" and not satd:
@@ -45,8 +50,7 @@ def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None):
         setattr(d, name, outs[name].data_ptr())
     torch.cuda.synchronize()
     rc = L.svt_hip_block_stats_batch(ctx._h, C.byref(d))
-    if rc:
-        raise api.SvtHipError(f"svt_hip_block_stats_batch: {rc} {ctx.last_error()}")
+    ctx.check(rc, "svt_hip_block_stats_batch")
     ctx.sync()
     res = {name: outs[name].cpu().numpy().view(dt) for name, dt in fields}
     if not satd:

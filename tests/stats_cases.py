@@ -34,3 +34,18 @@ def load_subpel_fixture():
     z = np.load(GOLDEN)
     jobs = np.ascontiguousarray(z["sp_jobs"]).view(abi.BLOCK_JOB_DTYPE).reshape(-1)
     return z["src8"], z["ref8"], jobs, {"variance": z["sp_variance"], "var_sse": z["sp_var_sse"]}
+
+
+# svt_spatial_full_distortion_kernel_facade columns of the fixture: name -> (temporal_layer_index, spy_rd, psy_rd); same table as oracle/gen_golden.py
+FACADE_SETTINGS = {"facade_a": (3, 1, PSY_RD), "facade_b": (5, 1, 0.0), "facade_c": (0, 1, 0.0), "facade_d": (4, 2, 0.0)}
+
+
+def load_facade_fixture(bd):
+    """(pred_mode, compound_type, {column: expected facade_dist}) of the jobs of load_fixture(bd)."""
+    z = np.load(GOLDEN)
+    return z[f"fac_mode{bd}"], z[f"fac_comp{bd}"], {k: z[f"{k}{bd}"] for k in FACADE_SETTINGS}
+
+
+def facade_arg(modes, comps, setting):
+    tli, spy, _ = FACADE_SETTINGS[setting]
+    return dict(pred_mode=modes, compound_type=comps, temporal_layer_index=tli, spy_rd=spy)

@@ -49,3 +49,19 @@ def test_bad_descriptor_is_rejected_without_a_gpu():
     assert L.svt_hip_me_config_from_preset(C.byref(pd), C.byref(cfg)) == 2
     assert L.svt_hip_input_resolution(3840, 2160) == 5 and L.svt_hip_input_resolution(1920, 1080) == 4
     assert L.svt_hip_input_resolution(352, 288) == 0
+
+
+def test_spy_rd_bias_host_function_matches_the_oracle(oracle):
+    """svt_hip_spy_rd_bias is host-only arithmetic (no GPU): every (mode, compound type, layer, size class, spy_rd, psy_rd) cell."""
+    L = api.lib()
+    L.svt_hip_spy_rd_bias.restype = C.c_uint64
+    oracle.orc_spy_rd_facade.restype = C.c_int64
+    for sse in (0, 1, 7, 123457, (1 << 40) + 12345):
+        for (w, h) in ((64, 64), (32, 32), (64, 32), (4, 4), (128, 128)):
+            for mode in range(25):
+                for comp in range(4):
+                    for tli in range(6):
+                        for spy, psy in ((1, 0.0), (1, 0.5), (2, 0.0), (0, 0.0)):
+                            a = L.svt_hip_spy_rd_bias(C.c_uint64(sse), w, h, mode, comp, tli, C.c_double(psy), spy)
+                            b = oracle.orc_spy_rd_facade(C.c_int64(sse), w, h, mode, comp, tli, C.c_double(psy), spy)
+                            assert a == b, (sse, w, h, mode, comp, tli, spy, psy)

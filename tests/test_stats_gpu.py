@@ -7,7 +7,7 @@ import numpy as np
 import pyoracle
 import pytest
 
-from stats_cases import PSY_RD, load_fixture, load_subpel_fixture, mismatches
+from stats_cases import FACADE_SETTINGS, PSY_RD, facade_arg, load_facade_fixture, load_fixture, load_subpel_fixture, mismatches
 from svt_av1_psyex_amd import abi, api, stats
 
 pytestmark = pytest.mark.gpu
@@ -55,6 +55,18 @@ def test_batch_rejects_bad_descriptors(hip_ctx):
     assert L.svt_hip_block_stats_batch(hip_ctx._h, C.byref(d)) == 2
     d = abi.BlockStatsDesc(bit_depth=8, n_jobs=0)
     assert L.svt_hip_block_stats_batch(hip_ctx._h, C.byref(d)) == 0
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_batch_facade_matches_reference_fixture(hip_ctx, bd):
+    """svt_spatial_full_distortion_kernel_facade (picture_operators_c.c:115-174) as the batch's facade_dist output."""
+    src, ref, jobs, _ = load_fixture(bd)
+    modes, comps, exp = load_facade_fixture(bd)
+    for k, (_, _, psy_rd) in FACADE_SETTINGS.items():
+        got = stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=False, psy_rd=psy_rd, facade=facade_arg(modes, comps, k))
+        assert np.array_equal(got["facade_dist"], exp[k]), k
+    with pytest.raises(api.SvtHipError):  # temporal_layer_index beyond the reference's weight table
+        stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=False, facade=dict(pred_mode=modes, compound_type=comps, temporal_layer_index=6, spy_rd=1))
 
 
 @pytest.fixture()
@@ -151,6 +163,33 @@ def test_leaf_psy_distortion(leaf, oracle):
             a2 = a16.reshape(-1)[1:]; b2 = b16.reshape(-1)[2:]
             want = int(float(oracle.orc_psy_distortion(p(a2), C.c_uint32(w + 3), p(b2), C.c_uint32(w + 5), C.c_uint32(w), C.c_uint32(hh), C.c_int(1))) * 0.75)
             assert got == want, (w, h)
+
+
+def test_leaf_psyex_facades(leaf, oracle):
+    """svt_spatial_full_distortion_kernel_facade_hip / svt_spatial_psy_distortion_kernel_hip with the reference's prototypes."""
+    leaf.svt_spatial_full_distortion_kernel_facade_hip.restype = leaf.svt_spatial_psy_distortion_kernel_hip.restype = C.c_uint64
+    oracle.orc_spy_rd_facade.restype = C.c_int64
+    oracle.orc_psy_distortion.restype = C.c_uint64
+    rng = np.random.default_rng(33)
+    for (w, h, mode, comp, tli) in [(64, 64, 0, 0, 3), (32, 32, 12, 1, 5), (16, 8, 9, 2, 2), (32, 64, 20, 3, 4), (8, 8, 16, 0, 1), (64, 64, 2, 0, 0)]:
+        a = rng.integers(0, 256, (h + 1, w + 7)).astype(np.uint8); b = rng.integers(0, 256, (h + 1, w + 2)).astype(np.uint8)
+        a2, b2 = a.reshape(-1)[3:].reshape(-1), b.reshape(-1)[1:].reshape(-1)
+        sse = int(((a.reshape(-1)[3:3 + h * (w + 7)].reshape(h, w + 7)[:, :w].astype(np.int64) - b.reshape(-1)[1:1 + h * (w + 2)].reshape(h, w + 2)[:, :w]) ** 2).sum())
+        for spy, psy in ((1, 0.0), (1, 1.0), (2, 0.0)):
+            want = oracle.orc_spy_rd_facade(C.c_int64(sse), C.c_uint32(w), C.c_uint32(h), C.c_uint8(mode), C.c_uint8(comp), C.c_uint8(tli), C.c_double(psy), C.c_uint8(spy))
+            got = leaf.svt_spatial_full_distortion_kernel_facade_hip(p(a), C.c_uint32(3), C.c_uint32(w + 7), p(b), C.c_int32(1), C.c_uint32(w + 2), C.c_uint32(w), C.c_uint32(h),
+                                                                     C.c_bool(False), C.c_uint8(mode), C.c_uint8(comp), C.c_uint8(tli), C.c_double(psy), C.c_uint8(spy))
+            assert got == want, (w, h, mode, comp, tli, spy, psy)
+        a16 = (a.astype(np.uint16) << 2) | 1; b16 = (b.astype(np.uint16) << 2) | 2
+        sse16 = int(((a16.reshape(-1)[3:3 + h * (w + 7)].reshape(h, w + 7)[:, :w].astype(np.int64) - b16.reshape(-1)[1:1 + h * (w + 2)].reshape(h, w + 2)[:, :w]) ** 2).sum())
+        want = oracle.orc_spy_rd_facade(C.c_int64(sse16), C.c_uint32(w), C.c_uint32(h), C.c_uint8(mode), C.c_uint8(comp), C.c_uint8(tli), C.c_double(0.0), C.c_uint8(1))
+        got = leaf.svt_spatial_full_distortion_kernel_facade_hip(p(a16), C.c_uint32(3), C.c_uint32(w + 7), p(b16), C.c_int32(1), C.c_uint32(w + 2), C.c_uint32(w), C.c_uint32(h),
+                                                                 C.c_bool(True), C.c_uint8(mode), C.c_uint8(comp), C.c_uint8(tli), C.c_double(0.0), C.c_uint8(1))
+        assert got == want, ("hbd", w, h, mode)
+        e = oracle.orc_psy_distortion(p(a2), C.c_uint32(w + 7), p(b2), C.c_uint32(w + 2), C.c_uint32(w), C.c_uint32(h), C.c_int(0))
+        for psy in (0.0, 0.6):
+            got = leaf.svt_spatial_psy_distortion_kernel_hip(p(a), C.c_uint32(3), C.c_uint32(w + 7), p(b), C.c_int32(1), C.c_uint32(w + 2), C.c_uint32(w), C.c_uint32(h), C.c_double(psy))
+            assert got == sse + (int(float(e) * psy) if psy > 0 else 0), (w, h, psy)
 
 
 def test_sub_pixel_variance_fixture_and_oracle(hip_ctx, oracle):
