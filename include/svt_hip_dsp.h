@@ -115,6 +115,9 @@ typedef struct SvtHipBlockStatsDesc {
     const uint8_t *pred_mode;     /* [n_jobs] PredictionMode of the candidate, device pointer; mandatory with facade_dist */
     const uint8_t *compound_type; /* [n_jobs] CompoundType, device pointer; mandatory with facade_dist */
     uint64_t      *facade_dist;   /* svt_spatial_full_distortion_kernel_facade: the SSE with the spy-rd mode biases */
+    /* svt_aom_highbd_10_variance{W}x{H}_c (Codec/svt_psnr.c:139-177), 10-bit planes only: sse and sum are brought back to the
+     * 8-bit scale with rounding ((sse + 8) >> 4, (sum + 2) >> 2) before sse - sum^2 / (w*h), clamped at 0 */
+    uint32_t *variance10, *var_sse10;
 } SvtHipBlockStatsDesc;
 
 /* The integer biases svt_spatial_full_distortion_kernel_facade applies to an SSE (picture_operators_c.c:130-171): host-only

@@ -89,6 +89,14 @@ SVT_HIP_DECL_SAD(64, 64) SVT_HIP_DECL_SAD(64, 128) SVT_HIP_DECL_SAD(128, 64) SVT
 #undef SVT_HIP_DECL_SAD
 /* svt_aom_variance_highbd_c (C_DEFAULT/variance.c:278-296) */
 uint32_t svt_aom_variance_highbd_hip(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse);
+/* svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:546-568, bodies Codec/svt_psnr.c:139-177): src / ref are CONVERT_TO_BYTEPTR'd
+ * uint16_t pointers, as the reference's callers pass them (av1me.c:31-172) */
+#define SVT_HIP_DECL_VAR10(W, H) unsigned int svt_aom_highbd_10_variance##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, unsigned int *sse);
+SVT_HIP_DECL_VAR10(4, 4) SVT_HIP_DECL_VAR10(4, 8) SVT_HIP_DECL_VAR10(4, 16) SVT_HIP_DECL_VAR10(8, 4) SVT_HIP_DECL_VAR10(8, 8) SVT_HIP_DECL_VAR10(8, 16)
+SVT_HIP_DECL_VAR10(8, 32) SVT_HIP_DECL_VAR10(16, 4) SVT_HIP_DECL_VAR10(16, 8) SVT_HIP_DECL_VAR10(16, 16) SVT_HIP_DECL_VAR10(16, 32) SVT_HIP_DECL_VAR10(16, 64)
+SVT_HIP_DECL_VAR10(32, 8) SVT_HIP_DECL_VAR10(32, 16) SVT_HIP_DECL_VAR10(32, 32) SVT_HIP_DECL_VAR10(32, 64) SVT_HIP_DECL_VAR10(64, 16) SVT_HIP_DECL_VAR10(64, 32)
+SVT_HIP_DECL_VAR10(64, 64) SVT_HIP_DECL_VAR10(64, 128) SVT_HIP_DECL_VAR10(128, 64) SVT_HIP_DECL_VAR10(128, 128)
+#undef SVT_HIP_DECL_VAR10
 
 /* coefficient-domain distortion (common_dsp_rtcd.h:160-161, aom_dsp_rtcd.h:212), residual (common_dsp_rtcd.h:157,170) */
 void    svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride,

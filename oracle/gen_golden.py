@@ -186,6 +186,18 @@ def gen_block_stats():
                                                                           C.c_uint8(tli), C.c_double(prd), C.c_uint8(spy))
         out.update({f"src{bd}": src, f"ref{bd}": refp, f"jobs{bd}": jobs.view(np.uint8).reshape(len(jobs), -1)})
         out.update({f"{k}{bd}": v for k, v in exp.items()})
+        if bd == 10:  # svt_aom_highbd_10_variance{W}x{H}_c on the AV1 shapes (pointers CONVERT_TO_BYTEPTR'd: address >> 1)
+            v10, s10, ok = np.zeros(len(jobs), np.uint32), np.zeros(len(jobs), np.uint32), np.zeros(len(jobs), np.uint8)
+            for j, jb in enumerate(jobs):
+                w, h = int(jb["width"]), int(jb["height"])
+                if (w, h) not in abi.VARIANCE_SIZES:
+                    continue
+                vs = C.c_uint32()
+                sa = src.ctypes.data + 2 * int(jb["src_offset"])
+                ra = refp.ctypes.data + 2 * int(jb["ref_offset"])
+                v10[j] = getattr(ref, f"svt_aom_highbd_10_variance{w}x{h}_c")(C.c_void_p(sa >> 1), W, C.c_void_p(ra >> 1), W, C.byref(vs)) & 0xFFFFFFFF
+                s10[j], ok[j] = vs.value, 1
+            out.update(hbd10_variance=v10, hbd10_var_sse=s10, hbd10_valid=ok)
         out.update({f"fac_mode{bd}": modes, f"fac_comp{bd}": comps})
         out.update({f"{k}{bd}": v for k, v in fac.items()})
     # sub-pixel variance (8-bit planes of above): AV1 variance shapes x all 64 phases, from svt_aom_sub_pixel_variance{W}x{H}_c

@@ -161,6 +161,10 @@ def block_stats(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None, facad
         for name, dt in abi.PSY_OUT_FIELDS:
             out[name] = np.zeros(n, dtype=dt)
             setattr(d, name, out[name].ctypes.data)
+    if bit_depth == 10:  # svt_aom_highbd_10_variance{W}x{H}
+        for name, dt in abi.VAR10_OUT_FIELDS:
+            out[name] = np.zeros(n, dtype=dt)
+            setattr(d, name, out[name].ctypes.data)
     if facade:  # dict(pred_mode, compound_type, temporal_layer_index, spy_rd): svt_spatial_full_distortion_kernel_facade
         modes, comps = np.ascontiguousarray(facade["pred_mode"], np.uint8), np.ascontiguousarray(facade["compound_type"], np.uint8)
         out["facade_dist"] = np.zeros(n, np.uint64)

@@ -161,6 +161,23 @@ uint32_t orc_sub_pixel_variance8(const uint8_t *a, int a_stride, int xoffset, in
     return v;
 }
 
+/* svt_aom_highbd_10_variance{W}x{H}_c = highbd_variance64 + highbd_10_variance + HIGHBD_VAR (Codec/svt_psnr.c:139-177):
+ * 64-bit sums of the 10-bit differences, both rounded back to the 8-bit scale, variance clamped at zero. */
+uint32_t orc_highbd_10_variance(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse) {
+    uint64_t sse_long = 0;
+    int64_t  sum_long = 0;
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const int diff = (int)a[(size_t)i * a_stride + j] - (int)b[(size_t)i * b_stride + j];
+            sum_long += diff;
+            sse_long += (uint32_t)(diff * diff);
+        }
+    *sse                = (uint32_t)((sse_long + 8) >> 4);
+    const int     sum   = (int)((sum_long + 2) >> 2);
+    const int64_t var   = (int64_t)*sse - ((int64_t)sum * sum) / (w * h);
+    return var >= 0 ? (uint32_t)var : 0;
+}
+
 /* svt_spatial_full_distortion_kernel_facade's spy-rd biases (C_DEFAULT/picture_operators_c.c:130-171) on an SSE already computed.
  * Enumerators: PredictionMode Codec/definitions.h:1126-1162 (DC 0, V 1, H 2, SMOOTH 9..11, PAETH 12, first inter 13, compound
  * 17..24), CompoundType :1197-1202 (AVERAGE 0, DISTWTD 1, WEDGE 2, DIFFWTD 3). */
@@ -188,6 +205,7 @@ int64_t orc_spy_rd_facade(int64_t dist, uint32_t w, uint32_t h, uint8_t mode, ui
 int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
     if (!d || (d->bit_depth != 8 && d->bit_depth != 10) || !d->src || !d->ref || !d->jobs) return 2;
     if (d->satd && d->bit_depth != 8) return 2;
+    if ((d->variance10 || d->var_sse10) && d->bit_depth != 10) return 2;
     for (uint32_t j = 0; j < d->n_jobs; j++) {
         const SvtHipBlockJob jb = d->jobs[j];
         const int w = jb.width, h = jb.height;
@@ -218,6 +236,12 @@ int orc_block_stats_batch(const SvtHipBlockStatsDesc *d) {
             sad = orc_sad_16b(s, s_stride, r, d->ref_stride, (uint32_t)h, (uint32_t)w);
             sse = orc_spatial_sse16(s, 0, s_stride, r, 0, d->ref_stride, (uint32_t)w, (uint32_t)h);
             var = orc_variance16(s, (int)s_stride, r, (int)d->ref_stride, w, h, &vsse);
+            if (d->variance10 || d->var_sse10) {
+                uint32_t s10;
+                const uint32_t v10 = orc_highbd_10_variance(s, (int)s_stride, r, (int)d->ref_stride, w, h, &s10);
+                if (d->variance10) d->variance10[j] = v10;
+                if (d->var_sse10) d->var_sse10[j] = s10;
+            }
         }
         if (d->psy_energy || d->psy_dist) {
             if ((w & 3) || (h & 3)) return 2;

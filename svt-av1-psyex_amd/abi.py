@@ -162,12 +162,14 @@ class BlockStatsDesc(C.Structure):
                 ("src", C.c_void_p), ("ref", C.c_void_p), ("jobs", C.c_void_p),
                 ("sad", C.c_void_p), ("sse", C.c_void_p), ("variance", C.c_void_p), ("var_sse", C.c_void_p), ("satd", C.c_void_p),
                 ("psy_rd", C.c_double), ("psy_energy", C.c_void_p), ("psy_dist", C.c_void_p),
-                ("psy_sse", C.c_void_p), ("pred_mode", C.c_void_p), ("compound_type", C.c_void_p), ("facade_dist", C.c_void_p)]
+                ("psy_sse", C.c_void_p), ("pred_mode", C.c_void_p), ("compound_type", C.c_void_p), ("facade_dist", C.c_void_p),
+                ("variance10", C.c_void_p), ("var_sse10", C.c_void_p)]
 
 
 BLOCK_JOB_DTYPE = [("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("subpel_x", "u1"), ("subpel_y", "u1")]
 STATS_OUT_FIELDS = [("sad", "<u4"), ("sse", "<u8"), ("variance", "<u4"), ("var_sse", "<u4"), ("satd", "<u4")]
 PSY_OUT_FIELDS = [("psy_energy", "<u8"), ("psy_dist", "<u8"), ("psy_sse", "<u8")]
 FACADE_OUT_FIELDS = [("facade_dist", "<u8")]
+VAR10_OUT_FIELDS = [("variance10", "<u4"), ("var_sse10", "<u4")]  # 10-bit planes only
 VARIANCE_SIZES = [(4, 4), (4, 8), (4, 16), (8, 4), (8, 8), (8, 16), (8, 32), (16, 4), (16, 8), (16, 16), (16, 32), (16, 64), (32, 8), (32, 16),
                   (32, 32), (32, 64), (64, 16), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128)]

@@ -280,6 +280,13 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         if (p.d.sse) p.d.sse[job] = sse;
         if (p.d.var_sse) p.d.var_sse[job] = sq32;
         if (p.d.variance) p.d.variance[job] = sq32 - (uint32_t)(((i64)sum * sum) / (w * h));
+        if (p.d.variance10 || p.d.var_sse10) { // highbd_10_variance (svt_psnr.c:160-177): rounding shifts, then the clamped variance
+            const uint32_t sse10 = (uint32_t)((sse + 8) >> 4);
+            const i64      sum10 = ((i64)sum + 2) >> 2;
+            const i64      var   = (i64)sse10 - (sum10 * sum10) / (w * h);
+            if (p.d.var_sse10) p.d.var_sse10[job] = sse10;
+            if (p.d.variance10) p.d.variance10[job] = var >= 0 ? (uint32_t)var : 0u;
+        }
         // svt_spatial_full_distortion_kernel_facade (picture_operators_c.c:115-174)
         if (p.d.facade_dist)
             p.d.facade_dist[job] = (u64)svt_hip_spy_rd_bias_inline((i64)sse, (uint32_t)w, (uint32_t)h, p.d.pred_mode[job], p.d.compound_type[job],
@@ -413,6 +420,7 @@ int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d)
     if (d->bit_depth != 8 && d->bit_depth != 10) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "bit_depth %u", d->bit_depth);
     if (!d->src || !d->ref || !d->jobs) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the block-stats batch is null");
     if (d->satd && d->bit_depth != 8) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "hadamard_path works on 8-bit input (enc_mode_config.c:2186)");
+    if ((d->variance10 || d->var_sse10) && d->bit_depth != 10) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "variance10 is defined on 10-bit planes");
     if (d->facade_dist && (!d->pred_mode || !d->compound_type || d->temporal_layer_index > 5))
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "facade_dist needs pred_mode, compound_type and temporal_layer_index <= 5 (got %u)", d->temporal_layer_index);
     hipSetDevice(ctx->device);
@@ -471,7 +479,7 @@ void upload_rows(SvtHipContext *ctx, void *dst, const void *src, size_t stride_b
     leaf_check(ctx, hipMemcpyAsync(dst, src, (rows - 1) * stride_bytes + row_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
 }
 
-struct StatsOut { uint32_t sad, variance, var_sse, satd; u64 sse, psy_energy, psy_dist; };
+struct StatsOut { uint32_t sad, variance, var_sse, satd; u64 sse, psy_energy, psy_dist; uint32_t variance10, var_sse10; };
 
 // one (src, ref) block through block_stats_kernel
 StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t ref_stride, int w, int h, int bit_depth, bool want_satd,
@@ -496,6 +504,7 @@ StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t 
     d.src = d_src; d.ref = d_ref; d.jobs = reinterpret_cast<const SvtHipBlockJob *>(d_job);
     StatsOut *o = reinterpret_cast<StatsOut *>(d_out);
     d.sad = &o->sad; d.variance = &o->variance; d.var_sse = &o->var_sse; d.sse = reinterpret_cast<uint64_t *>(&o->sse); d.satd = want_satd ? &o->satd : nullptr;
+    if (bit_depth == 10) { d.variance10 = &o->variance10; d.var_sse10 = &o->var_sse10; }
     if (want_psy) { d.psy_rd = psy_rd; d.psy_energy = reinterpret_cast<uint64_t *>(&o->psy_energy); d.psy_dist = reinterpret_cast<uint64_t *>(&o->psy_dist); }
     if (svt_hip_block_stats_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
     StatsOut out;
@@ -679,6 +688,20 @@ SVT_HIP_SAD(16, 4) SVT_HIP_SAD(16, 8) SVT_HIP_SAD(16, 16) SVT_HIP_SAD(16, 32) SV
 SVT_HIP_SAD(32, 32) SVT_HIP_SAD(32, 64) SVT_HIP_SAD(64, 16) SVT_HIP_SAD(64, 32) SVT_HIP_SAD(64, 64) SVT_HIP_SAD(64, 128) SVT_HIP_SAD(128, 64)
 SVT_HIP_SAD(128, 128)
 #undef SVT_HIP_SAD
+
+// svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:546-568): the uint8_t pointers carry uint16_t addresses >> 1 (CONVERT_TO_SHORTPTR)
+#define SVT_HIP_VAR10(W, H)                                                                                                           \
+    unsigned int svt_aom_highbd_10_variance##W##x##H##_hip(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, unsigned int *sse) { \
+        const StatsOut o = leaf_stats(reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(src8) << 1), (size_t)src_stride,  \
+                                      reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(ref8) << 1), (size_t)ref_stride, W, H, 10, false); \
+        *sse = o.var_sse10;                                                                                                            \
+        return o.variance10;                                                                                                           \
+    }
+SVT_HIP_VAR10(4, 4) SVT_HIP_VAR10(4, 8) SVT_HIP_VAR10(4, 16) SVT_HIP_VAR10(8, 4) SVT_HIP_VAR10(8, 8) SVT_HIP_VAR10(8, 16) SVT_HIP_VAR10(8, 32)
+SVT_HIP_VAR10(16, 4) SVT_HIP_VAR10(16, 8) SVT_HIP_VAR10(16, 16) SVT_HIP_VAR10(16, 32) SVT_HIP_VAR10(16, 64) SVT_HIP_VAR10(32, 8) SVT_HIP_VAR10(32, 16)
+SVT_HIP_VAR10(32, 32) SVT_HIP_VAR10(32, 64) SVT_HIP_VAR10(64, 16) SVT_HIP_VAR10(64, 32) SVT_HIP_VAR10(64, 64) SVT_HIP_VAR10(64, 128) SVT_HIP_VAR10(128, 64)
+SVT_HIP_VAR10(128, 128)
+#undef SVT_HIP_VAR10
 
 uint32_t svt_aom_variance_highbd_hip(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse) {
     const StatsOut o = leaf_stats(a, (size_t)a_stride, b, (size_t)b_stride, w, h, 10, false);

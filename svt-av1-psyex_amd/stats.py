@@ -32,13 +32,15 @@ def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None, facade=None)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
     n = len(jobs)
     t_src, t_ref, t_jobs = dev(src), dev(ref), dev(jobs)
-    fields = list(abi.STATS_OUT_FIELDS) + (list(abi.PSY_OUT_FIELDS) if psy_rd is not None else []) + (list(abi.FACADE_OUT_FIELDS) if facade else [])
+    fields = list(abi.STATS_OUT_FIELDS) + (list(abi.PSY_OUT_FIELDS) if psy_rd is not None else []) + (list(abi.FACADE_OUT_FIELDS) if facade else []) + (list(abi.VAR10_OUT_FIELDS) if bit_depth == 10 else [])
     outs = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in fields}
     d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
     if psy_rd is not None:
         d.psy_rd = psy_rd
         for name, _ in abi.PSY_OUT_FIELDS:
             setattr(d, name, outs[name].data_ptr())
+    if bit_depth == 10:
+        d.variance10, d.var_sse10 = outs["variance10"].data_ptr(), outs["var_sse10"].data_ptr()
     if facade:
         t_mode, t_comp = dev(np.asarray(facade["pred_mode"], np.uint8)), dev(np.asarray(facade["compound_type"], np.uint8))
         d.pred_mode, d.compound_type, d.facade_dist = t_mode.data_ptr(), t_comp.data_ptr(), outs["facade_dist"].data_ptr()

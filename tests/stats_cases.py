@@ -49,3 +49,9 @@ def load_facade_fixture(bd):
 def facade_arg(modes, comps, setting):
     tli, spy, _ = FACADE_SETTINGS[setting]
     return dict(pred_mode=modes, compound_type=comps, temporal_layer_index=tli, spy_rd=spy)
+
+
+def load_var10_fixture():
+    """10-bit jobs of load_fixture(10): svt_aom_highbd_10_variance{W}x{H}_c results and the mask of jobs with an AV1 variance shape."""
+    z = np.load(GOLDEN)
+    return z["hbd10_variance"], z["hbd10_var_sse"], z["hbd10_valid"].astype(bool)

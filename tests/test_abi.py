@@ -31,6 +31,8 @@ def test_library_exports_every_declared_symbol():
     # the variance entries are declared through a macro
     missing = [f"svt_aom_{k}variance{w}x{h}_hip" for (w, h) in abi.VARIANCE_SIZES for k in ("", "sub_pixel_") if not hasattr(L, f"svt_aom_{k}variance{w}x{h}_hip")]
     assert not missing, missing
+    missing = [f"svt_aom_highbd_10_variance{w}x{h}_hip" for (w, h) in abi.VARIANCE_SIZES if not hasattr(L, f"svt_aom_highbd_10_variance{w}x{h}_hip")]
+    assert not missing, missing
     missing = [f"svt_aom_sad{w}x{h}{k}_hip" for (w, h) in abi.VARIANCE_SIZES for k in ("", "x4d") if not hasattr(L, f"svt_aom_sad{w}x{h}{k}_hip")]
     assert not missing, missing
 

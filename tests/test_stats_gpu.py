@@ -7,7 +7,7 @@ import numpy as np
 import pyoracle
 import pytest
 
-from stats_cases import FACADE_SETTINGS, PSY_RD, facade_arg, load_facade_fixture, load_fixture, load_subpel_fixture, mismatches
+from stats_cases import load_var10_fixture, FACADE_SETTINGS, PSY_RD, facade_arg, load_facade_fixture, load_fixture, load_subpel_fixture, mismatches
 from svt_av1_psyex_amd import abi, api, stats
 
 pytestmark = pytest.mark.gpu
@@ -67,6 +67,31 @@ def test_batch_facade_matches_reference_fixture(hip_ctx, bd):
         assert np.array_equal(got["facade_dist"], exp[k]), k
     with pytest.raises(api.SvtHipError):  # temporal_layer_index beyond the reference's weight table
         stats.run_hip(hip_ctx, src, ref, jobs, bd, satd=False, facade=dict(pred_mode=modes, compound_type=comps, temporal_layer_index=6, spy_rd=1))
+
+
+def test_batch_highbd_10_variance(hip_ctx, oracle):
+    """svt_aom_highbd_10_variance{W}x{H} (svt_psnr.c:139-177): reference fixture on the AV1 shapes, oracle on every job."""
+    src, ref, jobs, _ = load_fixture(10)
+    v10, s10, ok = load_var10_fixture()
+    got = stats.run_hip(hip_ctx, src, ref, jobs, 10, satd=False)
+    want = pyoracle.block_stats(oracle, src, ref, jobs, 10, satd=False)
+    assert np.array_equal(got["variance10"][ok], v10[ok]) and np.array_equal(got["var_sse10"][ok], s10[ok])
+    assert np.array_equal(got["variance10"], want["variance10"]) and np.array_equal(got["var_sse10"], want["var_sse10"])
+    with pytest.raises(api.SvtHipError):  # 8-bit planes have no highbd_10 variance
+        d = abi.BlockStatsDesc(bit_depth=8, n_jobs=1, src=1, ref=1, jobs=1, variance10=1)
+        hip_ctx.check(api.lib().svt_hip_block_stats_batch(hip_ctx._h, C.byref(d)), "svt_hip_block_stats_batch")
+
+
+def test_leaf_highbd_10_variance(leaf, oracle):
+    rng = np.random.default_rng(77)
+    for (w, h) in abi.VARIANCE_SIZES:
+        a = rng.integers(0, 1024, (h, w + 6)).astype(np.uint16)
+        b = np.clip(a[:, :w + 2].astype(np.int32) + rng.integers(-300, 300, (h, w + 2)), 0, 1023).astype(np.uint16) if (w + h) % 3 else rng.integers(0, 1024, (h, w + 2)).astype(np.uint16)
+        b = np.ascontiguousarray(b)
+        s1, s2 = C.c_uint32(), C.c_uint32()
+        want = oracle.orc_highbd_10_variance(p(a), w + 6, p(b), w + 2, w, h, C.byref(s1))
+        got = getattr(leaf, f"svt_aom_highbd_10_variance{w}x{h}_hip")(C.c_void_p(a.ctypes.data >> 1), w + 6, C.c_void_p(b.ctypes.data >> 1), w + 2, C.byref(s2))
+        assert (got & 0xFFFFFFFF, s2.value) == (want & 0xFFFFFFFF, s1.value), (w, h)
 
 
 @pytest.fixture()
