@@ -1502,23 +1502,16 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 const u64       mean = d8 / 64;
                 const long long dd   = (long long)v8 - (long long)mean;
                 const u64       ssq  = wave_sum64((u64)(dd * dd));
-              if (tid == 0) {
-                const uint32_t pix = st.b64_w * st.b64_h;
-                p.res.me_8x8_cost_variance[b] = (uint32_t)(ssq / 64);
-                p.res.rc_me_distortion[b]     = d.input_resolution <= 2 ? d8 : d16;
-                p.res.me_64x64_distortion[b]  = (st.me_dist[0] * 4096u) / pix;
-                p.res.me_32x32_distortion[b]  = (d32 * 4096u) / pix;
-                p.res.me_16x16_distortion[b]  = (d16 * 4096u) / pix;
-                p.res.me_8x8_distortion[b]    = (d8 * 4096u) / pix;
+                // perform_gm_detection (:2838-2961): lane i classifies PU i of the list; the per-(list, ref, component, sign)
+                // counts of the reference's cnt[] are popcounts of ballots
                 uint8_t stationary = 0, allow_gm = 0;
-                if (d.gm_enabled) {
-                    uint32_t cnt[32]; // [list][ref][component][sign]
-                    for (int i = 0; i < 32; i++) cnt[i] = 0;
-                    uint32_t tot = 0, still = 0;
+                if (d.gm_enabled) { // uniform
                     const int low = d.input_resolution <= 2;
                     const int nn  = low ? 64 : 16;
-                    for (int i = 0; i < nn; i++) {
-                        int idx = (low ? 21 : 5) + i;
+                    int  refk = 0;
+                    bool neg_x = false, pos_x = false, neg_y = false, pos_y = false, still_l = false;
+                    if (tid < nn) {
+                        int idx = (low ? 21 : 5) + tid;
                         if (low && !d.enable_me_8x8) {
                             if (idx >= 21) idx = c_8x8_to_16x16[idx - 21];
                             if (!d.enable_me_16x16 && idx >= 5) idx = c_16x16_to_32x32[idx - 5];
@@ -1533,16 +1526,30 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                         else     { const int dist = (uint16_t)iabs((int)(int16_t)(a - bb)); th = d.gm_use_distance_based_active_th ? imax(dist * 16, 32) : 32; }
                         const uint32_t mv = st.best_mv[li][ri][idx];
                         const int mx = (int)(int16_t)(mv & 0xFFFF) << 2, my = (int)(int16_t)(mv >> 16) << 2;
-                        const int base = (int)(li * 4 + ri) * 4;
-                        if (mx < -th) cnt[base + 0]++; else if (mx > th) cnt[base + 1]++;
-                        if (my < -th) cnt[base + 2]++; else if (my > th) cnt[base + 3]++;
+                        refk  = (int)(li * 4 + ri);
+                        neg_x = mx < -th; pos_x = !neg_x && mx > th;
+                        neg_y = my < -th; pos_y = !neg_y && my > th;
                         const int sth = low ? 0 : 4;
-                        if (iabs(mx) <= sth && iabs(my) <= sth) still++;
-                        tot++;
+                        still_l = iabs(mx) <= sth && iabs(my) <= sth;
                     }
-                    if (still > (tot * 5) / 100) stationary = 1;
-                    for (int i = 0; i < 32; i++) if (cnt[i] > tot / 2) allow_gm = 1;
+                    const uint32_t tot = (uint32_t)nn;
+                    if ((uint32_t)__popcll(__ballot(still_l)) > (tot * 5) / 100) stationary = 1;
+                    const u64 bnx = __ballot(neg_x), bpx = __ballot(pos_x), bny = __ballot(neg_y), bpy = __ballot(pos_y);
+                    for (int k = 0; k < 8; k++) { // every (list, ref) a candidate can name
+                        const u64 m = __ballot(tid < nn && refk == k);
+                        if ((uint32_t)__popcll(m & bnx) > tot / 2 || (uint32_t)__popcll(m & bpx) > tot / 2 || (uint32_t)__popcll(m & bny) > tot / 2 ||
+                            (uint32_t)__popcll(m & bpy) > tot / 2)
+                            allow_gm = 1;
+                    }
                 }
+              if (tid == 0) {
+                const uint32_t pix = st.b64_w * st.b64_h;
+                p.res.me_8x8_cost_variance[b] = (uint32_t)(ssq / 64);
+                p.res.rc_me_distortion[b]     = d.input_resolution <= 2 ? d8 : d16;
+                p.res.me_64x64_distortion[b]  = (st.me_dist[0] * 4096u) / pix;
+                p.res.me_32x32_distortion[b]  = (d32 * 4096u) / pix;
+                p.res.me_16x16_distortion[b]  = (d16 * 4096u) / pix;
+                p.res.me_8x8_distortion[b]    = (d8 * 4096u) / pix;
                 p.res.stationary_block_present_sb[b] = stationary;
                 p.res.rc_me_allow_gm[b]              = allow_gm;
               }
