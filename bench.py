@@ -8,12 +8,13 @@ A *step* = one mini-GOP worth of 16 pictures of the sequence (4 current pictures
 temporal layers 4..1; R = 2 references per picture, one per list), each going through
   1. open-loop ME for every 64x64 block (== N x svt_aom_motion_estimation_b64); the pictures of the step are in
      flight together, as in the reference's ME threads, and share ONE launch (svt_hip_me_pictures_async),
-  2. full-pel motion-compensated 10-bit prediction from the ME winners (svt_hip_fullpel_pred, one launch per picture),
+  2. full-pel motion-compensated 10-bit prediction from the ME winners (svt_hip_fullpel_pred_batch, one launch for the step),
   3. the RD kernels on the 10-bit luma at three transform depths (64x64, 32x32, 16x16, DCT_DCT, "b" quantizer):
      residual -> fwd txfm -> SATD -> quantize -> coeff distortion -> inv txfm -> SSE (svt_hip_rd_batch; one batch per
      depth holds the blocks of all pictures of the step).
-With N GPUs the b64 rows of every picture are sharded across the ranks (all planes are replicated; no halo
-exchange) and the per-b64 ME results (MeSbResults arrays + the per-b64 scalars, ~1 KB per block) are all-gathered over
+With N GPUs the b64 rows of every picture are sharded across the ranks in contiguous bands (all planes are replicated; no
+halo exchange; the rows that do not divide by N rotate over the ranks from picture to picture, so every rank owns the same
+number of rows per step) and the per-b64 ME results (MeSbResults arrays + the per-b64 scalars, ~1 KB per block) are all-gathered over
 RCCL once per step, on a side stream behind the ME launch so that it overlaps the prediction / RD kernels.
 `value` = luma pixels of the pictures fully processed per second, whole job (strong scaling: the pictures per step
 are fixed, each rank handles 1/N of the b64 rows).
@@ -35,7 +36,7 @@ import torch  # noqa: E402
 from svt_av1_psyex_amd import abi, api, rd, shard, synth  # noqa: E402
 
 W, H = 3840, 2160
-DISTS = (1, 2, 4, 8)
+DISTS = (8, 1, 4, 2)  # long and short searches alternate: the per-XCD job queues of the ME launch (2 pictures each at N = 1) stay balanced
 LAYER = {1: 4, 2: 3, 4: 2, 8: 1}
 CURS = (8, 9, 10, 11)  # current pictures of one step; picture p = (CURS[p // 4], DISTS[p % 4])
 CUR = CURS[0]
@@ -64,43 +65,49 @@ class Workload:
         self.src10 = torch.from_numpy(np.stack([y10[c] for c in CURS]).astype(np.int16)).cuda().view(torch.int16).reshape(-1)
         self.y10 = {i: torch.from_numpy(y10[i].astype(np.int16)).cuda().view(torch.int16) for i in sorted({c - d for c, d in PICS})}
         self.w64, self.h64 = (W + 63) // 64, (H + 63) // 64
-        self.row0, self.row1 = shard.band(self.h64, rank, world)  # contiguous b64 row band of this rank
+        # contiguous b64 row band of this rank in every picture of the step; the rows that do not divide evenly rotate over the
+        # ranks from picture to picture (shard.rotation), so that every rank owns the same number of rows per step
+        self.bands = [shard.band(self.h64, rank, world, shard.rotation(pi, self.h64, world)) for pi in range(len(PICS))]
+        self.rows_per_step = sum(r1 - r0 for r0, r1 in self.bands)
         self.cfgs, self.descs = {}, {}
-        for cur, d in PICS:
+        for pi, (cur, d) in enumerate(PICS):
             self.cfgs[(cur, d)] = api.config_from_preset(6, W, H, qp=35, temporal_layer_index=LAYER[d], hierarchical_levels=4)
             desc = api.picture_desc(W, H, cur, {(0, 0): cur - d, (1, 0): cur + d}, enc_mode=6, temporal_layer_index=LAYER[d], hierarchical_levels=4)
-            desc.b64_row_start, desc.b64_row_count = self.row0, self.row1 - self.row0
+            desc.b64_row_start, desc.b64_row_count = self.bands[pi][0], self.bands[pi][1] - self.bands[pi][0]
             self.descs[(cur, d)] = desc
         self.n_pu = abi.n_pu(desc.enable_me_16x16, desc.enable_me_8x8)
         # ME results of the pictures of a step: ONE compact device buffer holding only this rank's b64 rows (padded to the
         # largest band so that every rank contributes the same byte count to the all-gather): shard.BandLayout.  The
         # search-level MVs that feed this rank's prediction stay in a local buffer.
         self.layout = shard.BandLayout(self.w64, self.h64, world, self.n_pu, desc.max_refs, desc.max_cand, n_pictures=len(PICS))
-        self.me_buf = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device="cuda")
+        # Two result buffers, used by alternate steps: the exchange of step k may still be reading its buffer while the ME launch
+        # of step k + 1 fills the other one.
+        self.me_bufs = [torch.zeros(self.layout.nbytes, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+        self.me_buf = self.me_bufs[0]
         nb = self.w64 * self.h64
         self.mv_buf = torch.zeros(len(PICS) * nb * 680, dtype=torch.int32, device="cuda")
-        self.me_res, self.mv_ptr = {}, {}
+        self.me_res, self.mv_ptr = [{} for _ in self.me_bufs], {}
         for pi, pic in enumerate(PICS):
-            self.me_res[pic] = self.layout.results_struct(self.me_buf.data_ptr(), pi, rank)
             self.mv_ptr[pic] = self.mv_buf.data_ptr() + pi * nb * 680 * 4
-            self.me_res[pic].sb_best_mv = self.mv_ptr[pic]
+            for k, buf in enumerate(self.me_bufs):
+                self.me_res[k][pic] = self.layout.results_struct(buf.data_ptr(), pi, rank)
+                self.me_res[k][pic].sb_best_mv = self.mv_ptr[pic]
         # RD: one prediction / recon plane per picture of the step (contiguous, so that one batch addresses all of them) and
         # job lists restricted to this rank's rows
         NP = len(PICS)
         self.pred = torch.zeros(NP * H * W, dtype=torch.int16, device="cuda")
         self.recon = torch.zeros(NP * H * W, dtype=torch.int16, device="cuda")
         self.rows = torch.from_numpy(np.stack([rd.quant_row_from_step(140, 176)]).view(np.uint8).reshape(-1)).cuda()
-        y_lo, y_hi = self.row0 * 64, min(self.row1 * 64, H)
         self.rd = []
         self.rd_pixels = 0
         for ts in RD_SIZES:
             jobs = rd.grid_jobs(W, H, W, ts)
             ys = (jobs["src_offset"] // W).astype(np.int64)
-            keep = (ys >= y_lo) & (ys < y_hi)  # bands are whole b64 rows, so a block never straddles two ranks
-            one = np.ascontiguousarray(jobs[keep])
             allp = []
             for pi in range(NP):
-                j = one.copy()
+                y_lo, y_hi = self.bands[pi][0] * 64, min(self.bands[pi][1] * 64, H)
+                keep = (ys >= y_lo) & (ys < y_hi)  # bands are whole b64 rows, so a block never straddles two ranks
+                j = np.ascontiguousarray(jobs[keep]).copy()
                 j["src_offset"] += (pi // len(DISTS)) * H * W  # its current picture
                 j["pred_offset"] += pi * H * W                 # its prediction / recon plane
                 allp.append(j)
@@ -114,30 +121,34 @@ class Workload:
                 setattr(d, name, t.data_ptr())
             self.rd.append((ts, d, t_jobs, outs, n))
             self.rd_pixels += n * abi.TX_W[ts] * abi.TX_H[ts]  # per step (all pictures)
-        self.me_jobs = [(self.cfgs[pic], self.descs[pic], self.pics[pic[0]], self.refs(pic), self.me_res[pic]) for pic in PICS]
+        self.me_jobs = [[(self.cfgs[pic], self.descs[pic], self.pics[pic[0]], self.refs(pic), res[pic]) for pic in PICS] for res in self.me_res]
+        # full-pel prediction of all pictures of the step: one launch
+        self.pred_jobs = (abi.PredJob * NP)()
+        for pi, (cur, d) in enumerate(PICS):
+            pj = self.pred_jobs[pi]
+            pj.ref, pj.sb_best_mv, pj.pred = self.y10[cur - d].data_ptr(), self.mv_ptr[(cur, d)], self.pred.data_ptr() + 2 * pi * H * W
+            pj.b64_row_start, pj.b64_row_count, pj.list, pj.ref_idx = self.bands[pi][0], self.bands[pi][1] - self.bands[pi][0], 0, 0
         torch.cuda.synchronize()
-        log(f"[rank {rank}] setup {time.time() - t0:.1f}s: rows {self.row0}..{self.row1} of {self.h64}, RD jobs {[r[4] for r in self.rd]}")
+        log(f"[rank {rank}] setup {time.time() - t0:.1f}s: {self.rows_per_step} of {self.h64 * NP} b64 rows per step, RD jobs {[r[4] for r in self.rd]}")
 
     def refs(self, pic):
         cur, d = pic
         return {(0, 0): self.pics[cur - d], (1, 0): self.pics[cur + d]}
 
-    def step(self, ev=None, after_me=None):
+    def step(self, ev=None, after_me=None, k=0):
         """Enqueue one step on the context stream.  `ev`: optional dict collecting (start, end) event pairs per kernel family;
-        `after_me`: callback run right behind the ME launch (the multi-GPU exchange hooks in there)."""
+        `after_me`: callback run right behind the ME launch (the multi-GPU exchange hooks in there); `k`: result buffer."""
         L = api.lib()
         mark = lambda: None
         if ev is not None:
             def mark():
                 e = torch.cuda.Event(enable_timing=True); e.record(); return e
         e0 = mark()
-        self.ctx.me_pictures_async(self.me_jobs)
+        self.ctx.me_pictures_async(self.me_jobs[k])
         e1 = mark()
         if after_me is not None:
             after_me()
-        for pi, (cur, d) in enumerate(PICS):
-            self.ctx.check(L.svt_hip_fullpel_pred(self.ctx._h, C.c_void_p(self.y10[cur - d].data_ptr()), W, W, H, 10, C.c_void_p(self.mv_ptr[(cur, d)]), 0, 0,
-                                                  self.row0, self.row1 - self.row0, C.c_void_p(self.pred.data_ptr() + 2 * pi * H * W), W), "svt_hip_fullpel_pred")
+        self.ctx.check(L.svt_hip_fullpel_pred_batch(self.ctx._h, W, W, H, 10, W, len(self.pred_jobs), self.pred_jobs), "svt_hip_fullpel_pred_batch")
         e2 = mark()
         for ts, desc, _, _, n in self.rd:
             if n:
@@ -250,8 +261,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = api.Context(local_rank)
     ext = torch.cuda.ExternalStream(ctx.stream)
-    wl = Workload(ctx, rank, world)
-    gather_out = torch.zeros(world * wl.me_buf.numel(), dtype=torch.uint8, device="cuda") if world > 1 else None
+    # SVT_BENCH_EMULATE_RANK="r/N" (development aid, never set by the driver): a single process does the share of rank r of N
+    # -- its row band, its job lists -- without any exchange, to read a rank's compute time at N GPUs off a one-GPU box
+    emu = os.environ.get("SVT_BENCH_EMULATE_RANK")
+    wl = Workload(ctx, *(map(int, emu.split("/")) if emu and world == 1 else (rank, world)))
+    gather_outs = [torch.zeros(world * b.numel(), dtype=torch.uint8, device="cuda") for b in wl.me_bufs] if world > 1 else None
+    landed = [None, None]  # event of the last exchange that read result buffer k
+    step_no = [0]
 
     def barrier():
         if world > 1:
@@ -261,29 +277,34 @@ def main():
 
     comm = torch.cuda.Stream() if world > 1 else None
 
-    def exchange():
+    def exchange(k):
         # per-b64 best-cost / MV / candidate results of this rank's rows -> every rank (RCCL over xGMI), on a side stream
-        # ordered behind the ME launch; the prediction / RD kernels of the step overlap it
+        # ordered behind the ME launch; the prediction / RD kernels of the step -- and the next step's ME launch, which
+        # writes the other result buffer -- overlap it
         done = torch.cuda.Event()
         done.record(ext)
         with torch.cuda.stream(comm):
             comm.wait_event(done)
             if rehearsal:
-                host = wl.me_buf.cpu()
+                host = wl.me_bufs[k].cpu()
                 parts = [torch.zeros_like(host) for _ in range(world)]
                 dist.all_gather(parts, host)
-                gather_out.copy_(torch.cat(parts), non_blocking=True)
+                gather_outs[k].copy_(torch.cat(parts), non_blocking=True)
             else:
-                dist.all_gather_into_tensor(gather_out, wl.me_buf)
+                dist.all_gather_into_tensor(gather_outs[k], wl.me_bufs[k])
+            landed[k] = torch.cuda.Event()
+            landed[k].record(comm)
 
     def run(steps, ev=None):
         with torch.cuda.stream(ext):
             for _ in range(steps):
-                if world > 1:
-                    ext.wait_stream(comm)  # the previous exchange has read the result buffer this step's ME overwrites
-                wl.step(ev, exchange if world > 1 else None)
+                k = step_no[0] % len(wl.me_bufs)
+                step_no[0] += 1
+                if world > 1 and landed[k] is not None:
+                    ext.wait_event(landed[k])  # the exchange two steps back has read the result buffer this step's ME overwrites
+                wl.step(ev, (lambda k=k: exchange(k)) if world > 1 else None, k)
         if world > 1:
-            ext.wait_stream(comm)          # the timed region ends when the last exchange has landed
+            ext.wait_stream(comm)              # the timed region ends when the last exchange has landed
 
     run(a.warmup)
     barrier()
@@ -297,15 +318,16 @@ def main():
     barrier()
     kms = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in ev.items()}
     if rehearsal and world > 1 and rank == 0:
-        # the gathered buffers of all ranks, unpacked, must equal a whole-picture run (picture 0 of the step)
-        pic = PICS[0]
-        whole_desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[pic]))
-        whole_desc.b64_row_start, whole_desc.b64_row_count = 0, 0
-        whole = ctx.me_picture(wl.cfgs[pic], whole_desc, wl.pics[pic[0]], wl.refs(pic), search_level=False)
-        merged = wl.layout.unpack(gather_out.cpu().numpy(), 0)
-        bad = [k for k in merged if not np.array_equal(np.asarray(whole[k]).reshape(merged[k].shape), merged[k])]
-        log("rehearsal: gathered results of picture 0 " + ("MATCH a whole-picture run" if not bad else f"DIFFER in {bad}"))
-        assert not bad, bad
+        # the gathered buffers of all ranks, unpacked, must equal a whole-picture run (two pictures with different band rotations)
+        for pi in (0, 5):
+            pic = PICS[pi]
+            whole_desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[pic]))
+            whole_desc.b64_row_start, whole_desc.b64_row_count = 0, 0
+            whole = ctx.me_picture(wl.cfgs[pic], whole_desc, wl.pics[pic[0]], wl.refs(pic), search_level=False)
+            merged = wl.layout.unpack(gather_outs[(step_no[0] - 1) % 2].cpu().numpy(), pi)
+            bad = [k for k in merged if not np.array_equal(np.asarray(whole[k]).reshape(merged[k].shape), merged[k])]
+            log(f"rehearsal: gathered results of picture {pi} " + ("MATCH a whole-picture run" if not bad else f"DIFFER in {bad}"))
+            assert not bad, bad
     t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         if rehearsal:
@@ -316,7 +338,7 @@ def main():
     value = pictures * W * H / dt / 1e6
     if rank == 0:
         R = 2
-        frac_rows = (wl.row1 - wl.row0) / wl.h64
+        frac_rows = wl.rows_per_step / (wl.h64 * len(PICS))
         me_bytes = (1.3125 * (1 + R) + 0.166 * R) * W * H * frac_rows * len(PICS)  # B_ME bytes per pixel x the pictures of one launch
         rd_bytes = wl.rd_pixels * (2 * 2 + 4 + 2)  # B_RD = 2*bpp + 4 (+bpp recon), bpp = 2; the step's three launches
         dom = "me" if kms["me"] >= kms["rd"] / len(RD_SIZES) else "rd"  # the single kernel with the longest launch
@@ -333,7 +355,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u8 SAD / i32 transforms", "data": "synthetic",
             "config": {"workload": "3840x2160 10-bit synthetic pan sequence, preset 6 (M6) search controls at qp 35; step = 16 pictures (4 current pictures x ref distance 1,2,4,8; R=2): "
                                    "open-loop ME of all 2040 b64 + full-pel pred + RD chain (64x64,32x32,16x16 DCT_DCT, 10-bit, b quantizer)",
-                       "pictures_per_step": len(PICS), "b64_rows_per_rank": wl.row1 - wl.row0, "parallelism": f"b64-row bands x{world} + all-gather of ME results"},
+                       "pictures_per_step": len(PICS), "b64_rows_per_rank_per_step": wl.rows_per_step, "parallelism": f"b64-row bands x{world} (left-over rows rotating over the ranks) + all-gather of ME results"},
             "roofline": {"bound": "hbm", "kernel": "svt_hip_me_b64_kernel" if dom == "me" else "rd_tx_kernel (3 sizes)", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(me_bytes if dom == "me" else rd_bytes), "avg_launch_ms": round(kms[dom], 4)},

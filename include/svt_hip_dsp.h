@@ -137,6 +137,19 @@ int svt_hip_fullpel_pred(SvtHipContext *ctx, const void *ref, uint32_t ref_strid
                          const uint32_t *sb_best_mv, uint8_t list, uint8_t ref_idx, uint32_t b64_row_start, uint32_t b64_row_count,
                          void *pred, uint32_t pred_stride); /* b64_row_count == 0: all rows from b64_row_start */
 
+/* Several pictures in one launch (at most SVT_HIP_PRED_MAX_JOBS): all share the plane geometry; per job the reference plane, the
+ * MV array, the prediction plane and the row band.  Host array of jobs holding device pointers. */
+#define SVT_HIP_PRED_MAX_JOBS 16
+typedef struct SvtHipPredJob {
+    const void     *ref;
+    const uint32_t *sb_best_mv;
+    void           *pred;
+    uint32_t        b64_row_start, b64_row_count; /* count 0: all rows from b64_row_start */
+    uint8_t         list, ref_idx, reserved[6];
+} SvtHipPredJob;
+int svt_hip_fullpel_pred_batch(SvtHipContext *ctx, uint32_t ref_stride, uint32_t width, uint32_t height, uint8_t bit_depth, uint32_t pred_stride,
+                               uint32_t n_jobs, const SvtHipPredJob *jobs);
+
 /* Scan order of (tx_size, tx_type) as av1_scan_orders holds it (Codec/coefficients.h:2197); returns the length. */
 int svt_hip_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan);
 int svt_hip_tx_size_wide(int tx_size);

@@ -94,6 +94,12 @@ class MeResults(C.Structure):
     ]
 
 
+class PredJob(C.Structure):
+    """SvtHipPredJob (include/svt_hip_dsp.h)."""
+    _fields_ = [("ref", C.c_void_p), ("sb_best_mv", C.c_void_p), ("pred", C.c_void_p), ("b64_row_start", C.c_uint32), ("b64_row_count", C.c_uint32),
+                ("list", C.c_uint8), ("ref_idx", C.c_uint8), ("reserved", C.c_uint8 * 6)]
+
+
 class DgMetrics(C.Structure):
     """SvtHipDgMetrics (include/svt_hip_me.h)."""
     _fields_ = [("tot_dist", C.c_uint64), ("tot_cplx", C.c_uint32), ("tot_active", C.c_uint32), ("sum_in_vectors", C.c_int32),

@@ -671,12 +671,11 @@ int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d) {
 namespace {
 // one workgroup per 64x64 block; a thread copies runs of 8 samples (one 8- or 16-byte store; the source run starts at an
 // arbitrary sample, so its load is unaligned) and falls back to per-sample clamping where the run touches a picture edge
-template <typename Pix> __global__ void __launch_bounds__(256) fullpel_pred_kernel(const Pix *ref, uint32_t ref_stride, int width, int height,
-                                                                                   const uint32_t *sb_best_mv, int list, int ref_idx, uint32_t w64, int by64_first,
-                                                                                   Pix *pred, uint32_t pred_stride, int vec_ok) {
+template <typename Pix> __device__ __forceinline__ void fullpel_pred_b64(const Pix *ref, uint32_t ref_stride, int width, int height, const uint32_t *sb_best_mv,
+                                                                         int list, int ref_idx, uint32_t w64, int bx, int by, Pix *pred, uint32_t pred_stride,
+                                                                         int vec_ok) {
     typedef Pix __attribute__((ext_vector_type(8), aligned(sizeof(Pix)))) RunU; // unaligned run of 8 samples
     typedef Pix __attribute__((ext_vector_type(8))) Run;
-    const int bx = blockIdx.x, by = by64_first + (int)blockIdx.y;
     const uint32_t b = (uint32_t)bx + (uint32_t)by * w64;
     const uint32_t *mvs = sb_best_mv + ((size_t)b * 8 + list * 4 + ref_idx) * 85 + 5; // the 16 16x16 PUs, quad-tree order
     for (int seg = threadIdx.x; seg < 64 * 8; seg += 256) {
@@ -701,6 +700,24 @@ template <typename Pix> __global__ void __launch_bounds__(256) fullpel_pred_kern
         }
     }
 }
+
+template <typename Pix> __global__ void __launch_bounds__(256) fullpel_pred_kernel(const Pix *ref, uint32_t ref_stride, int width, int height,
+                                                                                   const uint32_t *sb_best_mv, int list, int ref_idx, uint32_t w64, int by64_first,
+                                                                                   Pix *pred, uint32_t pred_stride, int vec_ok) {
+    fullpel_pred_b64<Pix>(ref, ref_stride, width, height, sb_best_mv, list, ref_idx, w64, (int)blockIdx.x, by64_first + (int)blockIdx.y, pred, pred_stride, vec_ok);
+}
+
+// several pictures in one launch (blockIdx.z = picture): the per-picture launches of a row band are launch-bound
+struct PredBatch {
+    SvtHipPredJob job[SVT_HIP_PRED_MAX_JOBS];
+};
+template <typename Pix> __global__ void __launch_bounds__(256) fullpel_pred_batch_kernel(const PredBatch pb, uint32_t ref_stride, int width, int height, uint32_t w64,
+                                                                                         uint32_t pred_stride, int vec_ok) {
+    const SvtHipPredJob &j = pb.job[blockIdx.z];
+    if (blockIdx.y >= j.b64_row_count) return;
+    fullpel_pred_b64<Pix>(static_cast<const Pix *>(j.ref), ref_stride, width, height, j.sb_best_mv, j.list, j.ref_idx, w64, (int)blockIdx.x,
+                          (int)(j.b64_row_start + blockIdx.y), static_cast<Pix *>(j.pred), pred_stride, vec_ok);
+}
 } // namespace
 
 extern "C" int svt_hip_fullpel_pred(SvtHipContext *ctx, const void *ref, uint32_t ref_stride, uint32_t width, uint32_t height, uint8_t bit_depth,
@@ -721,6 +738,35 @@ extern "C" int svt_hip_fullpel_pred(SvtHipContext *ctx, const void *ref, uint32_
     else
         hipLaunchKernelGGL(fullpel_pred_kernel<uint16_t>, g, blk, 0, ctx->stream, static_cast<const uint16_t *>(ref), ref_stride, (int)width, (int)height,
                            sb_best_mv, (int)list, (int)ref_idx, w64, (int)b64_row_start, static_cast<uint16_t *>(pred), pred_stride, vec_ok);
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_fullpel_pred_batch(SvtHipContext *ctx, uint32_t ref_stride, uint32_t width, uint32_t height, uint8_t bit_depth, uint32_t pred_stride,
+                                          uint32_t n_jobs, const SvtHipPredJob *jobs) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    if (!jobs || n_jobs == 0 || n_jobs > SVT_HIP_PRED_MAX_JOBS || (bit_depth != 8 && bit_depth != 10) || !width || !height)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "svt_hip_fullpel_pred_batch: bad argument (1..%d jobs)", SVT_HIP_PRED_MAX_JOBS);
+    const uint32_t w64 = (width + 63) / 64, h64 = (height + 63) / 64;
+    const size_t   bpp = bit_depth == 8 ? 1 : 2;
+    PredBatch pb;
+    memset(&pb, 0, sizeof(pb));
+    uint32_t rows_max = 0;
+    int      vec_ok   = pred_stride % 8 == 0;
+    for (uint32_t i = 0; i < n_jobs; i++) {
+        SvtHipPredJob j = jobs[i];
+        if (!j.ref || !j.sb_best_mv || !j.pred || j.list > 1 || j.ref_idx > 3 || j.b64_row_start >= h64)
+            return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "svt_hip_fullpel_pred_batch: job %u: null pointer, list / ref_idx or b64_row_start %u out of range", i,
+                                j.b64_row_start);
+        if (j.b64_row_count == 0 || j.b64_row_start + j.b64_row_count > h64) j.b64_row_count = h64 - j.b64_row_start;
+        rows_max = j.b64_row_count > rows_max ? j.b64_row_count : rows_max;
+        vec_ok   = vec_ok && (reinterpret_cast<uintptr_t>(j.pred) % (8 * bpp)) == 0;
+        pb.job[i] = j;
+    }
+    hipSetDevice(ctx->device);
+    const dim3 g(w64, rows_max, n_jobs), blk(256);
+    if (bit_depth == 8) hipLaunchKernelGGL(fullpel_pred_batch_kernel<uint8_t>, g, blk, 0, ctx->stream, pb, ref_stride, (int)width, (int)height, w64, pred_stride, vec_ok);
+    else hipLaunchKernelGGL(fullpel_pred_batch_kernel<uint16_t>, g, blk, 0, ctx->stream, pb, ref_stride, (int)width, (int)height, w64, pred_stride, vec_ok);
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }

@@ -61,3 +61,40 @@ def test_fullpel_pred(hip_ctx, bd, w, h, stride_pad):
 
 def test_fullpel_pred_rejects_bad_arguments(hip_ctx):
     assert api.lib().svt_hip_fullpel_pred(hip_ctx._h, None, 64, 64, 64, 10, None, 0, 0, 0, 0, None, 64) == 2
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_fullpel_pred_batch_equals_single_launches(hip_ctx, bd):
+    """svt_hip_fullpel_pred_batch: several pictures (own reference, MVs, prediction plane, row band) in one launch."""
+    import torch
+    from svt_av1_psyex_amd import abi
+    w, h = 712, 400
+    h64, nb = (h + 63) // 64, ((w + 63) // 64) * ((h + 63) // 64)
+    dt = np.uint8 if bd == 8 else np.uint16
+    rng = np.random.default_rng(5 + bd)
+    bands = [(0, 0), (2, 3), (6, 1), (1, 4), (0, 7)]  # (row_start, row_count): whole picture, inner bands, the last (partial) row
+    refs, mvs, preds, keep = [], [], [], []
+    jobs = (abi.PredJob * len(bands))()
+    for i, (r0, nr) in enumerate(bands):
+        ref = rng.integers(0, 1 << bd, (h, w)).astype(dt)
+        mv = ((rng.integers(-40, 41, (nb, 8, 85)).astype(np.int64) & 0xFFFF) << 16 | (rng.integers(-90, 91, (nb, 8, 85)).astype(np.int64) & 0xFFFF)).astype(np.uint32)
+        t_ref = torch.from_numpy(ref.view(np.uint8).reshape(-1).copy()).cuda()
+        t_mv = torch.from_numpy(mv.view(np.uint8).reshape(-1).copy()).cuda()
+        t_pred = torch.zeros(h * w * ref.itemsize, dtype=torch.uint8, device="cuda")
+        keep += [t_ref, t_mv, t_pred]
+        refs.append(ref); mvs.append(mv); preds.append(t_pred)
+        jobs[i].ref, jobs[i].sb_best_mv, jobs[i].pred = t_ref.data_ptr(), t_mv.data_ptr(), t_pred.data_ptr()
+        jobs[i].b64_row_start, jobs[i].b64_row_count, jobs[i].list, jobs[i].ref_idx = r0, nr, i & 1, i % 4
+    torch.cuda.synchronize()
+    hip_ctx.check(api.lib().svt_hip_fullpel_pred_batch(hip_ctx._h, w, w, h, bd, w, len(bands), jobs), "svt_hip_fullpel_pred_batch")
+    hip_ctx.sync()
+    for i, (r0, nr) in enumerate(bands):
+        rows = nr if nr else h64 - r0
+        got = preds[i].cpu().numpy().view(dt).reshape(h, w)
+        want = _expected(refs[i], mvs[i], i & 1, i % 4, r0, rows)
+        y0, y1 = r0 * 64, min((r0 + rows) * 64, h)
+        assert np.array_equal(got[y0:y1], want[y0:y1]), i
+        assert not got[:y0].any() and not got[y1:].any(), i
+    assert api.lib().svt_hip_fullpel_pred_batch(hip_ctx._h, w, w, h, bd, w, 17, jobs) == 2  # more than SVT_HIP_PRED_MAX_JOBS
+    jobs[1].b64_row_start = h64
+    assert api.lib().svt_hip_fullpel_pred_batch(hip_ctx._h, w, w, h, bd, w, len(bands), jobs) == 2

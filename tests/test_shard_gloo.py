@@ -32,8 +32,8 @@ def _worker(rank, world, port, q):
         w64, h64 = 10, 6
         lay = shard.BandLayout(w64, h64, world, abi.n_pu(d.enable_me_16x16, d.enable_me_8x8), d.max_refs, d.max_cand, n_pictures=2)
         buf = np.zeros(lay.nbytes, np.uint8)
-        r0, r1 = shard.band(h64, rank, world)
-        for pic in range(2):  # two pictures in one exchange, as bench.py does with four
+        for pic in range(2):  # two pictures in one exchange (bench.py: sixteen); the left-over rows rotate between them
+            r0, r1 = lay.band(pic, rank)
             d.b64_row_start, d.b64_row_count = r0, r1 - r0
             res = lay.results_struct(buf.ctypes.data, pic, rank)
             rc = pyoracle.load_oracle().orc_me_picture(C.byref(case.cfg), C.byref(d), case.cur.descs(), pyoracle.ref_plane_array(case.refs), C.byref(res))
@@ -71,6 +71,12 @@ def test_band_sharding_and_all_gather(world):
 def test_bands_cover_every_row_once():
     for h64 in (5, 17, 34):
         for world in (1, 2, 3, 4, 8):
-            rows = [r for k in range(world) for r in range(*shard.band(h64, k, world))]
-            assert rows == list(range(h64))
-            assert shard.rows_max(h64, world) * world >= h64
+            for rot in range(world):
+                rows = [r for k in range(world) for r in range(*shard.band(h64, k, world, rot))]
+                assert rows == list(range(h64))
+                sizes = [shard.band(h64, k, world, rot)[1] - shard.band(h64, k, world, rot)[0] for k in range(world)]
+                assert max(sizes) == shard.rows_max(h64, world) and max(sizes) - min(sizes) <= 1
+            # over `world` consecutive pictures every rank owns the same number of rows
+            tot = [sum(shard.band(h64, k, world, shard.rotation(p, h64, world))[1] - shard.band(h64, k, world, shard.rotation(p, h64, world))[0]
+                       for p in range(world)) for k in range(world)]
+            assert len(set(tot)) == 1 and tot[0] == h64
