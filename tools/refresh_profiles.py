@@ -16,7 +16,7 @@ def short(k):
     if 'rd_tx_kernel' in k:
         return 'rd_tx_kernel<%s>' % k.split('rd_tx_kernel<')[1].split('>')[0]
     if 'fullpel' in k:
-        return 'fullpel_pred_kernel'
+        return 'fullpel_pred_batch_kernel'
     return None
 
 
