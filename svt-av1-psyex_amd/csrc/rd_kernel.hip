@@ -362,6 +362,9 @@ __host__ __device__ constexpr int rd_blocks_per_wave(int ts) { return 64 / rd_la
 // =========================================================================================================
 // resident waves per SIMD the register allocation aims for: enough workgroups in flight that a picture's blocks of one size
 // run as a single round (e.g. 32x32: 4,020 two-block workgroups on 256 CUs x 4 SIMDs x 4 waves)
+#ifndef SVT_RD_WAVES_64
+#define SVT_RD_WAVES_64 2
+#endif
 #ifndef SVT_RD_WAVES_32
 #define SVT_RD_WAVES_32 4
 #endif
@@ -369,7 +372,7 @@ __host__ __device__ constexpr int rd_blocks_per_wave(int ts) { return 64 / rd_la
 #define SVT_RD_WAVES_16 4
 #endif
 __host__ __device__ constexpr int rd_waves_per_simd(int ts) {
-    return rd_lanes_per_block(ts) == 64 ? 2 : rd_lanes_per_block(ts) == 32 ? SVT_RD_WAVES_32 : SVT_RD_WAVES_16;
+    return rd_lanes_per_block(ts) == 64 ? SVT_RD_WAVES_64 : rd_lanes_per_block(ts) == 32 ? SVT_RD_WAVES_32 : SVT_RD_WAVES_16;
 }
 template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_simd(TS)) rd_tx_kernel(const RdParams p) {
     constexpr int W = tx_wide(TS), H = tx_high(TS), WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
