@@ -52,6 +52,19 @@ SVT_HIP_DECL_SPVAR(32, 8) SVT_HIP_DECL_SPVAR(32, 16) SVT_HIP_DECL_SPVAR(32, 32) 
 SVT_HIP_DECL_SPVAR(64, 64) SVT_HIP_DECL_SPVAR(64, 128) SVT_HIP_DECL_SPVAR(128, 64) SVT_HIP_DECL_SPVAR(128, 128)
 #undef SVT_HIP_DECL_SPVAR
 
+/* The 8x8-based SAD pyramid of the integer search (aom_dsp_rtcd.h:842-855; Codec/motion_estimation.c:98-425, me_sad_calculation.c:14) */
+void svt_ext_all_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8,
+                                               uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8],
+                                               uint32_t p_eight_sad8x8[64][8], bool sub_sad);
+void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64,
+                                                   uint32_t *p_best_mv32x32, uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]);
+void svt_ext_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t *p_best_sad_8x8,
+                                           uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16,
+                                           uint32_t *p_sad8x8, bool sub_sad);
+void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
+                                             uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32);
+void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value);
+
 /* svt_aom_sse (aom_dsp_rtcd.h:53), svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (common_dsp_rtcd.h:164-168) */
 int64_t  svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height);
 uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,

@@ -813,3 +813,168 @@ int svt_hip_estimate_transform(int16_t *residual, uint32_t residual_stride, int3
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// The 8x8-based SAD pyramid of the integer search as pointer-level entries (aom_dsp_rtcd.h:842-855; bodies
+// Codec/motion_estimation.c:98-425).  In production these live inside svt_hip_me_b64_kernel; here one small launch per call.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ExtSadParams {
+    const uint8_t *src, *ref;
+    uint32_t       src_stride, ref_stride, mv;
+    int            n16, npos, sub_sad;
+    uint32_t      *best8, *best16, *mv8, *mv16, *sad16, *sad8;
+};
+
+__device__ __forceinline__ uint32_t mv_plus_x(uint32_t mv, int k) {
+    const int16_t x = (int16_t)((int16_t)(mv & 0xFFFF) + (int16_t)k);
+    return (mv & 0xFFFF0000u) | (uint16_t)x;
+}
+
+// lane = 8x8 block in the order of the best arrays: (16x16 in the reference's PU order) * 4 + quadrant (motion_estimation.c:341)
+__global__ void __launch_bounds__(64) ext_sad_8x8_16x16_kernel(const ExtSadParams p) {
+    const int  lane = threadIdx.x, z16 = lane >> 2, q = lane & 3;
+    const bool live = z16 < p.n16;
+    const int  z2r[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; // raster <-> PU order of the 16x16s (its own inverse)
+    const int  b   = p.n16 == 16 ? z2r[z16 & 15] : 0;
+    const int  row = (b >> 2) * 16 + (q >> 1) * 8, col = (b & 3) * 16 + (q & 1) * 8;
+    uint32_t best = live ? p.best8[lane] : 0, bmv = live ? p.mv8[lane] : 0;
+    uint32_t b16 = (live && q == 0) ? p.best16[z16] : 0, m16 = (live && q == 0) ? p.mv16[z16] : 0;
+    for (int k = 0; k < p.npos; k++) {
+        uint32_t v = 0;
+        if (live) {
+            const int step = p.sub_sad ? 2 : 1; // svt_aom_compute8x4_sad_kernel_c on every other row, doubled (:42-91,105-136)
+            for (int r = 0; r < 8; r += step)
+                for (int c = 0; c < 8; c++) {
+                    const int d = (int)p.src[(size_t)(row + r) * p.src_stride + col + c] - (int)p.ref[(size_t)(row + r) * p.ref_stride + col + c + k];
+                    v += (uint32_t)(d < 0 ? -d : d);
+                }
+            if (p.sub_sad) v <<= 1;
+            if (v < best) { best = v; bmv = mv_plus_x(p.mv, k); }
+            if (p.sad8 && p.npos == 1) p.sad8[lane] = v;
+        }
+        uint32_t total = v + __shfl_xor(v, 1, 64);
+        total += __shfl_xor(total, 2, 64);
+        if (live && q == 0) {
+            p.sad16[z16 * p.npos + k] = total;
+            if (total < b16) { b16 = total; m16 = mv_plus_x(p.mv, k); }
+        }
+    }
+    if (live) { p.best8[lane] = best; p.mv8[lane] = bmv; }
+    if (live && q == 0) { p.best16[z16] = b16; p.mv16[z16] = m16; }
+}
+
+// svt_ext_{eight_,}sad_calculation_32x32_64x64 (:171-205,369-425): sums of four 16x16 SADs per 32x32, of four 32x32 per 64x64
+__global__ void ext_sad_32x32_64x64_kernel(const uint32_t *sad16, int npos, uint32_t mv, uint32_t *best32, uint32_t *best64, uint32_t *mv32, uint32_t *mv64,
+                                           uint32_t *sad32) {
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < npos; k++) {
+        uint32_t total = 0;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t s = sad16[(4 * q) * npos + k] + sad16[(4 * q + 1) * npos + k] + sad16[(4 * q + 2) * npos + k] + sad16[(4 * q + 3) * npos + k];
+            sad32[q * npos + k] = s;
+            if (s < best32[q]) { best32[q] = s; mv32[q] = mv_plus_x(mv, k); }
+            total += s;
+        }
+        if (total < best64[0]) { best64[0] = total; mv64[0] = mv_plus_x(mv, k); }
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, uint32_t n, uint32_t v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void leaf_ext_8x8_16x16(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *best8, uint32_t *best16,
+                        uint32_t *mv8, uint32_t *mv16, uint32_t *sad16, uint32_t *sad8, bool sub_sad, int n16, int npos) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    const int    side = n16 == 16 ? 64 : 16, n8 = n16 * 4;
+    const size_t sbytes = ((size_t)side - 1) * src_stride + side, rbytes = ((size_t)side - 1) * ref_stride + side + npos - 1;
+    const size_t sb = align256(sbytes), rb = align256(rbytes);
+    uint8_t *base = leaf_scratch(ctx, sb + rb + 4096);
+    uint32_t *d_u = reinterpret_cast<uint32_t *>(base + sb + rb); // best8[64] best16[16] mv8[64] mv16[16] sad16[128] sad8[64]
+    leaf_check(ctx, hipMemcpyAsync(base, src, sbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(base + sb, ref, rbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u, best8, n8 * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u + 64, best16, n16 * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u + 80, mv8, n8 * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u + 144, mv16, n16 * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    ExtSadParams p;
+    p.src = base; p.ref = base + sb; p.src_stride = src_stride; p.ref_stride = ref_stride; p.mv = mv; p.n16 = n16; p.npos = npos; p.sub_sad = sub_sad ? 1 : 0;
+    p.best8 = d_u; p.best16 = d_u + 64; p.mv8 = d_u + 80; p.mv16 = d_u + 144; p.sad16 = d_u + 160; p.sad8 = sad8 ? d_u + 288 : nullptr;
+    hipLaunchKernelGGL(ext_sad_8x8_16x16_kernel, dim3(1), dim3(64), 0, ctx->stream, p);
+    leaf_check(ctx, hipGetLastError(), "ext_sad_8x8_16x16_kernel launch");
+    leaf_check(ctx, hipMemcpyAsync(best8, d_u, n8 * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(best16, d_u + 64, n16 * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(mv8, d_u + 80, n8 * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(mv16, d_u + 144, n16 * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(sad16, d_u + 160, (size_t)n16 * npos * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    if (sad8) leaf_check(ctx, hipMemcpyAsync(sad8, d_u + 288, n8 * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+void leaf_ext_32x32_64x64(const uint32_t *sad16, int npos, uint32_t mv, uint32_t *best32, uint32_t *best64, uint32_t *mv32, uint32_t *mv64, uint32_t *sad32) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    uint32_t *d_u = reinterpret_cast<uint32_t *>(leaf_scratch(ctx, 2048)); // sad16[128] best32[4] best64[1] mv32[4] mv64[1] sad32[32]
+    leaf_check(ctx, hipMemcpyAsync(d_u, sad16, (size_t)16 * npos * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u + 128, best32, 16, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u + 132, best64, 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u + 136, mv32, 16, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_u + 140, mv64, 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    hipLaunchKernelGGL(ext_sad_32x32_64x64_kernel, dim3(1), dim3(64), 0, ctx->stream, d_u, npos, mv, d_u + 128, d_u + 132, d_u + 136, d_u + 140, d_u + 144);
+    leaf_check(ctx, hipGetLastError(), "ext_sad_32x32_64x64_kernel launch");
+    leaf_check(ctx, hipMemcpyAsync(best32, d_u + 128, 16, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(best64, d_u + 132, 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(mv32, d_u + 136, 16, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(mv64, d_u + 140, 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(sad32, d_u + 144, (size_t)4 * npos * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+} // namespace
+
+extern "C" {
+
+void svt_ext_all_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8,
+                                               uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8],
+                                               uint32_t p_eight_sad8x8[64][8], bool sub_sad) {
+    (void)p_eight_sad8x8; // left untouched, like the C body (motion_estimation.c:335-362 never stores to it)
+    leaf_ext_8x8_16x16(src, src_stride, ref, ref_stride, mv, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, &p_eight_sad16x16[0][0], nullptr,
+                       sub_sad, 16, 8);
+}
+
+void svt_ext_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t *p_best_sad_8x8,
+                                           uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16,
+                                           uint32_t *p_sad8x8, bool sub_sad) {
+    leaf_ext_8x8_16x16(src, src_stride, ref, ref_stride, mv, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, p_sad16x16, p_sad8x8, sub_sad, 1, 1);
+}
+
+void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
+                                                   uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]) {
+    leaf_ext_32x32_64x64(&p_sad16x16[0][0], 8, mv, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, &p_sad32x32[0][0]);
+}
+
+void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
+                                             uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32) {
+    leaf_ext_32x32_64x64(p_sad16x16, 1, mv, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, p_sad32x32);
+}
+
+void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) {
+    const uint32_t n = count128 * 4 + count32; // me_sad_calculation.c:14-17
+    if (!n) return;
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    uint32_t *d = reinterpret_cast<uint32_t *>(leaf_scratch(ctx, (size_t)n * 4));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, n, value);
+    leaf_check(ctx, hipGetLastError(), "fill_u32_kernel launch");
+    leaf_check(ctx, hipMemcpyAsync(pointer, d, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+} // extern "C"

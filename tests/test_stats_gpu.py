@@ -308,3 +308,40 @@ def test_leaf_coefficient_distortion_residual_and_estimate_transform(leaf, oracl
                 e = oracle.orc_handle_transform(p(full), C.c_int(ts))
                 assert np.array_equal(got, full[:got.size]), (ts, tt, pf)
                 assert tq.value == (0 if pf else e), (ts, tt, pf)
+
+
+@pytest.mark.parametrize("sub_sad", [0, 1])
+def test_leaf_ext_sad_family(leaf, oracle, sub_sad):
+    """svt_ext_{all,eight}_sad_calculation_* and the single-point forms (motion_estimation.c:98-425) + svt_initialize_buffer_32bits:
+    same random grid as the oracle-vs-reference test (tests/test_oracle_vs_ref.py::test_ext_sad_family)."""
+    rng = np.random.default_rng(11)
+    for it in range(12):
+        stride_s, stride_r = 64 + int(rng.integers(0, 9)), 80 + int(rng.integers(0, 9))
+        src = rng.integers(0, 256, (64, stride_s), dtype=np.uint8)
+        refp = rng.integers(0, 256, (64, stride_r), dtype=np.uint8)
+        if it % 5 == 0:
+            refp[:, :64] = src[:, :64]  # ties / zero SADs
+        mv = int(rng.integers(0, 1 << 32))
+        if it % 2:
+            init = rng.integers(0, 20000, 85).astype(np.uint32)
+        else:
+            init = np.zeros(85, np.uint32)
+            leaf.svt_initialize_buffer_32bits_hip(p(init), C.c_uint32(21), C.c_uint32(1), C.c_uint32(128 * 128 * 255))  # 21 * 4 + 1 = 85 (motion_estimation.c:1366)
+            assert (init == 128 * 128 * 255).all()
+        res = []
+        for lib, pre, suf in ((leaf, "svt_ext_", "_hip"), (oracle, "orc_ext_", "")):
+            bs, bm = init.copy(), np.zeros(85, np.uint32)
+            e16, e8, e32 = np.zeros((16, 8), np.uint32), np.zeros((64, 8), np.uint32), np.zeros((4, 8), np.uint32)
+            getattr(lib, pre + "all_sad_calculation_8x8_16x16" + suf)(p(src), C.c_uint32(stride_s), p(refp), C.c_uint32(stride_r), C.c_uint32(mv), p(bs[21:]), p(bs[5:]),
+                                                                     p(bm[21:]), p(bm[5:]), p(e16), p(e8), C.c_bool(bool(sub_sad)))
+            getattr(lib, pre + "eight_sad_calculation_32x32_64x64" + suf)(p(e16), p(bs[1:]), p(bs), p(bm[1:]), p(bm), C.c_uint32(mv), p(e32))
+            s16, s8 = np.zeros(16, np.uint32), np.zeros(64, np.uint32)
+            bs2, bm2 = init.copy(), np.zeros(85, np.uint32)
+            getattr(lib, pre + "sad_calculation_8x8_16x16" + suf)(p(src), C.c_uint32(stride_s), p(refp), C.c_uint32(stride_r), p(bs2[21:]), p(bs2[5:]), p(bm2[21:]),
+                                                                 p(bm2[5:]), C.c_uint32(mv), p(s16), p(s8), C.c_bool(bool(sub_sad)))
+            s32 = np.zeros(4, np.uint32)
+            s16full = e16[:, 0].copy()
+            getattr(lib, pre + "sad_calculation_32x32_64x64" + suf)(p(s16full), p(bs2[1:]), p(bs2), p(bm2[1:]), p(bm2), C.c_uint32(mv), p(s32))
+            res.append((bs, bm, e16, e8, e32, bs2, bm2, s16[:1], s8[:4], s32))
+        for i, (a, b) in enumerate(zip(*res)):
+            assert np.array_equal(a, b), (it, i)
