@@ -65,6 +65,31 @@ void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_b
                                              uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32);
 void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value);
 
+/* Quantizers (aom_dsp_rtcd.h:244-263; Codec/full_loop.c:29-79,149-198 "b", :282-474 "fp"): TranLow = int32_t, QmVal = uint8_t; the
+ * table rows are MacroblockPlane rows ([0] = DC, [1] = AC); eob from iscan (the inverse of scan, as every av1_scan_orders entry is) */
+#define SVT_HIP_DECL_QUANT_B(NAME)                                                                                                                    \
+    void NAME(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,              \
+              const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,               \
+              const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, const int32_t log_scale);
+SVT_HIP_DECL_QUANT_B(svt_aom_quantize_b_hip) SVT_HIP_DECL_QUANT_B(svt_aom_highbd_quantize_b_hip)
+SVT_HIP_DECL_QUANT_B(svt_av1_quantize_b_qm_hip) SVT_HIP_DECL_QUANT_B(svt_av1_highbd_quantize_b_qm_hip)
+#undef SVT_HIP_DECL_QUANT_B
+#define SVT_HIP_DECL_QUANT_FP(NAME)                                                                                                                   \
+    void NAME(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,              \
+              const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,               \
+              const int16_t *scan, const int16_t *iscan);
+SVT_HIP_DECL_QUANT_FP(svt_av1_quantize_fp_hip) SVT_HIP_DECL_QUANT_FP(svt_av1_quantize_fp_32x32_hip) SVT_HIP_DECL_QUANT_FP(svt_av1_quantize_fp_64x64_hip)
+#undef SVT_HIP_DECL_QUANT_FP
+void svt_av1_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
+void svt_av1_highbd_quantize_fp_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                    const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                    const int16_t *scan, const int16_t *iscan, int16_t log_scale);
+void svt_av1_highbd_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                       const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                       const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
+
 /* svt_aom_sse (aom_dsp_rtcd.h:53), svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (common_dsp_rtcd.h:164-168) */
 int64_t  svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height);
 uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,

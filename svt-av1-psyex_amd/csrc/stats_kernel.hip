@@ -978,3 +978,149 @@ void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Quantizers as pointer-level entries (aom_dsp_rtcd.h:244-263; bodies Codec/full_loop.c:29-79,149-198 ("b"), :282-474 ("fp")).
+// In production they are a stage of rd_tx_kernel; here one launch over a caller-supplied coefficient array.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct QuantLeafParams {
+    const int32_t *coeff;
+    int32_t       *qcoeff, *dqcoeff;
+    uint32_t      *eob;
+    const int16_t *iscan;
+    const uint8_t *qm, *iqm; // null = flat (1 << AOM_QM_BITS)
+    int            n, log_scale, hbd, fp;
+    int16_t        zbin[2], round[2], quant[2], quant_shift[2], dequant[2]; // [0] = DC, [1] = AC; round / quant are the fp rows when fp
+};
+
+__global__ void __launch_bounds__(256) quantize_leaf_kernel(const QuantLeafParams p) {
+    __shared__ uint32_t s_eob;
+    if (threadIdx.x == 0) s_eob = 0;
+    __syncthreads();
+    const int ls = p.log_scale;
+    uint32_t  eob = 0;
+    for (int rc = threadIdx.x; rc < p.n; rc += 256) {
+        const int     ac = rc != 0;
+        const int32_t co = p.coeff[rc], sign = co < 0 ? -1 : 0, a = (co ^ sign) - sign;
+        const int32_t wt = p.qm ? p.qm[rc] : 32, iwt = p.iqm ? p.iqm[rc] : 32; // AOM_QM_BITS = 5
+        const int32_t rnd = ls ? ((p.round[ac] + (1 << (ls - 1))) >> ls) : p.round[ac];
+        int32_t qv = 0, dq = 0;
+        if (!p.fp) { // svt_aom_quantize_b_c_ii / svt_aom_highbd_quantize_b_c
+            const int32_t zb = ls ? ((p.zbin[ac] + (1 << (ls - 1))) >> ls) : p.zbin[ac];
+            if ((i64)a * wt >= ((i64)zb << 5)) {
+                i64 t = (i64)a + rnd;
+                if (!p.hbd) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+                t *= wt;
+                qv = (int32_t)(((((t * p.quant[ac]) >> 16) + t) * p.quant_shift[ac]) >> (16 - ls + 5));
+                dq = (qv * (((int32_t)p.dequant[ac] * iwt + 16) >> 5)) >> ls;
+            }
+        } else if (!p.qm && !p.iqm) { // quantize_fp_helper_c / highbd_quantize_fp_helper_c, flat
+            const bool keep = p.hbd ? ((a << (1 + ls)) >= p.dequant[ac]) : (((i64)a << (1 + ls)) >= (int32_t)p.dequant[ac]);
+            if (keep) {
+                i64 t = (i64)a + rnd;
+                if (!p.hbd) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+                qv = (int32_t)((t * p.quant[ac]) >> (16 - ls));
+                dq = (qv * (int32_t)p.dequant[ac]) >> ls;
+            }
+        } else if ((i64)a * wt >= ((int32_t)p.dequant[ac] << (5 - (1 + ls)))) { // the helpers' matrix branch
+            i64 t = (i64)a + rnd;
+            if (!p.hbd) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+            qv = (int32_t)((t * p.quant[ac] * wt) >> (16 - ls + 5));
+            dq = (qv * (((int32_t)p.dequant[ac] * iwt + 16) >> 5)) >> ls;
+        }
+        p.qcoeff[rc]  = (qv ^ sign) - sign;
+        p.dqcoeff[rc] = (dq ^ sign) - sign;
+        if (qv) { const uint32_t e = (uint32_t)p.iscan[rc] + 1; eob = e > eob ? e : eob; }
+    }
+    atomicMax(&s_eob, eob);
+    __syncthreads();
+    if (threadIdx.x == 0) *p.eob = s_eob;
+}
+
+void leaf_quantize(const int32_t *coeff, intptr_t n, const int16_t *zbin, const int16_t *round, const int16_t *quant, const int16_t *quant_shift, int32_t *qcoeff,
+                   int32_t *dqcoeff, const int16_t *dequant, uint16_t *eob, const int16_t *iscan, const uint8_t *qm, const uint8_t *iqm, int log_scale, int hbd,
+                   int fp) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    *eob = 0;
+    if (n <= 0) return;
+    const size_t cb = align256((size_t)n * 4), ib = align256((size_t)n * 2), mb = align256((size_t)n);
+    uint8_t *base = leaf_scratch(ctx, 3 * cb + ib + 2 * mb + 256);
+    QuantLeafParams p;
+    memset(&p, 0, sizeof(p));
+    p.coeff = reinterpret_cast<int32_t *>(base); p.qcoeff = reinterpret_cast<int32_t *>(base + cb); p.dqcoeff = reinterpret_cast<int32_t *>(base + 2 * cb);
+    p.iscan = reinterpret_cast<int16_t *>(base + 3 * cb);
+    uint8_t *d_qm = base + 3 * cb + ib, *d_iqm = d_qm + mb;
+    p.eob = reinterpret_cast<uint32_t *>(d_iqm + mb);
+    leaf_check(ctx, hipMemcpyAsync(base, coeff, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(base + 3 * cb, iscan, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    if (qm) { leaf_check(ctx, hipMemcpyAsync(d_qm, qm, (size_t)n, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync"); p.qm = d_qm; }
+    if (iqm) { leaf_check(ctx, hipMemcpyAsync(d_iqm, iqm, (size_t)n, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync"); p.iqm = d_iqm; }
+    p.n = (int)n; p.log_scale = log_scale; p.hbd = hbd; p.fp = fp;
+    for (int k = 0; k < 2; k++) { // MacroblockPlane rows: [0] = DC, [1..7] = AC
+        p.zbin[k] = zbin ? zbin[k] : 0; p.round[k] = round[k]; p.quant[k] = quant[k]; p.quant_shift[k] = quant_shift ? quant_shift[k] : 0; p.dequant[k] = dequant[k];
+    }
+    hipLaunchKernelGGL(quantize_leaf_kernel, dim3(1), dim3(256), 0, ctx->stream, p);
+    leaf_check(ctx, hipGetLastError(), "quantize_leaf_kernel launch");
+    uint32_t e = 0;
+    leaf_check(ctx, hipMemcpyAsync(qcoeff, p.qcoeff, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(dqcoeff, p.dqcoeff, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(&e, p.eob, 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    *eob = (uint16_t)e;
+}
+
+} // namespace
+
+extern "C" {
+
+#define SVT_HIP_QUANT_B(NAME, HBD)                                                                                                                        \
+    void NAME(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,                 \
+              const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, \
+              const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, const int32_t log_scale) {                                            \
+        (void)scan;                                                                                                                                      \
+        leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, qm_ptr, iqm_ptr, \
+                      log_scale, HBD, 0);                                                                                                                \
+    }
+SVT_HIP_QUANT_B(svt_aom_quantize_b_hip, 0)
+SVT_HIP_QUANT_B(svt_aom_highbd_quantize_b_hip, 1)
+SVT_HIP_QUANT_B(svt_av1_quantize_b_qm_hip, 0)
+SVT_HIP_QUANT_B(svt_av1_highbd_quantize_b_qm_hip, 1)
+#undef SVT_HIP_QUANT_B
+
+#define SVT_HIP_QUANT_FP(NAME, LS)                                                                                                                       \
+    void NAME(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,                 \
+              const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, \
+              const int16_t *iscan) {                                                                                                                    \
+        (void)scan;                                                                                                                                      \
+        leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, nullptr, nullptr, \
+                      LS, 0, 1);                                                                                                                         \
+    }
+SVT_HIP_QUANT_FP(svt_av1_quantize_fp_hip, 0)
+SVT_HIP_QUANT_FP(svt_av1_quantize_fp_32x32_hip, 1)
+SVT_HIP_QUANT_FP(svt_av1_quantize_fp_64x64_hip, 2)
+#undef SVT_HIP_QUANT_FP
+
+void svt_av1_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale) {
+    (void)scan;
+    leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, qm_ptr, iqm_ptr, log_scale, 0, 1);
+}
+void svt_av1_highbd_quantize_fp_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                    const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                    const int16_t *scan, const int16_t *iscan, int16_t log_scale) {
+    (void)scan;
+    leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, nullptr, nullptr, log_scale, 1, 1);
+}
+void svt_av1_highbd_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
+                                       const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+                                       const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale) {
+    (void)scan;
+    leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, qm_ptr, iqm_ptr, log_scale, 1, 1);
+}
+
+} // extern "C"

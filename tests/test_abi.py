@@ -33,6 +33,11 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     missing = [f"svt_aom_highbd_10_variance{w}x{h}_hip" for (w, h) in abi.VARIANCE_SIZES if not hasattr(L, f"svt_aom_highbd_10_variance{w}x{h}_hip")]
     assert not missing, missing
+    quant = ["svt_aom_quantize_b_hip", "svt_aom_highbd_quantize_b_hip", "svt_av1_quantize_b_qm_hip", "svt_av1_highbd_quantize_b_qm_hip", "svt_av1_quantize_fp_hip",
+             "svt_av1_quantize_fp_32x32_hip", "svt_av1_quantize_fp_64x64_hip", "svt_av1_quantize_fp_qm_hip", "svt_av1_highbd_quantize_fp_hip",
+             "svt_av1_highbd_quantize_fp_qm_hip"]
+    missing = [s for s in quant if not hasattr(L, s)]
+    assert not missing, missing
     missing = [f"svt_aom_sad{w}x{h}{k}_hip" for (w, h) in abi.VARIANCE_SIZES for k in ("", "x4d") if not hasattr(L, f"svt_aom_sad{w}x{h}{k}_hip")]
     assert not missing, missing
 

@@ -345,3 +345,51 @@ def test_leaf_ext_sad_family(leaf, oracle, sub_sad):
             res.append((bs, bm, e16, e8, e32, bs2, bm2, s16[:1], s8[:4], s32))
         for i, (a, b) in enumerate(zip(*res)):
             assert np.array_equal(a, b), (it, i)
+
+
+def _quant_rows(rng, dc, ac):
+    """int16[8] MacroblockPlane-style rows ([0] = DC, [1..7] = AC) of an rd.quant_row_from_step quantizer."""
+    from svt_av1_psyex_amd import rd
+    r = rd.quant_row_from_step(dc, ac)
+    row = lambda k: np.array([r[k][0]] + [r[k][1]] * 7, np.int16)
+    return {k: row(k) for k in ("zbin", "round", "quant", "quant_shift", "round_fp", "quant_fp", "dequant")}
+
+
+@pytest.mark.parametrize("tx_size,log_scale", [(0, 0), (2, 0), (8, 0), (3, 1), (9, 1), (4, 2), (11, 2)])
+def test_leaf_quantizers(leaf, oracle, tx_size, log_scale):
+    """The ten quantizer pointers (aom_dsp_rtcd.h:244-263) against oracle/dsp_oracle.c (itself pinned on the reference's `_c` bodies):
+    real scan orders, flat and random matrices, zero / DC-only / extreme / random coefficients (test/quantize_func_test.cc patterns)."""
+    rng = np.random.default_rng(100 + tx_size)
+    n = min(api.lib().svt_hip_tx_size_wide(tx_size), 32) * min(api.lib().svt_hip_tx_size_high(tx_size), 32)
+    scan, iscan = np.zeros(n, np.int16), np.zeros(n, np.int16)
+    assert api.lib().svt_hip_scan_order(tx_size, 0, p(scan), p(iscan)) == n
+    for case, (dc, ac) in enumerate([(8, 9), (60, 75), (300, 410), (1336, 1828)]):
+        t = _quant_rows(rng, dc, ac)
+        for pat in ("random", "zero", "dc", "extreme", "small"):
+            co = {"random": rng.integers(-40000, 40000, n), "zero": np.zeros(n), "dc": np.r_[rng.integers(-90000, 90000), np.zeros(n - 1)],
+                  "extreme": rng.choice([-(1 << 20), (1 << 20) - 1], n), "small": rng.integers(-ac, ac + 1, n)}[pat].astype(np.int32)
+            qm, iqm = rng.integers(16, 256, n).astype(np.uint8), rng.integers(16, 256, n).astype(np.uint8)
+            for hbd in (0, 1):
+                for use_qm in (0, 1):
+                    m, im = (p(qm), p(iqm)) if use_qm else (None, None)
+                    # "b": svt_aom_{highbd_,}quantize_b and the _qm pointers share the prototype
+                    for name in (("svt_aom_highbd_quantize_b_hip", "svt_av1_highbd_quantize_b_qm_hip") if hbd else ("svt_aom_quantize_b_hip", "svt_av1_quantize_b_qm_hip")):
+                        q1, d1, q2, d2 = (np.full(n, 7, np.int32) for _ in range(4))
+                        e1, e2 = C.c_uint16(99), C.c_uint16(99)
+                        getattr(leaf, name)(p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round"]), p(t["quant"]), p(t["quant_shift"]), p(q1), p(d1), p(t["dequant"]),
+                                            C.byref(e1), p(scan), p(iscan), m, im, C.c_int32(log_scale))
+                        oracle.orc_quantize_b(p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round"]), p(t["quant"]), p(t["quant_shift"]), p(q2), p(d2), p(t["dequant"]),
+                                              C.byref(e2), p(scan), m, im, log_scale, hbd)
+                        assert e1.value == e2.value and np.array_equal(q1, q2) and np.array_equal(d1, d2), (name, case, pat, use_qm)
+                    # "fp"
+                    q1, d1, q2, d2 = (np.full(n, 7, np.int32) for _ in range(4))
+                    e1, e2 = C.c_uint16(99), C.c_uint16(99)
+                    common = (p(co), C.c_ssize_t(n), p(t["zbin"]), p(t["round_fp"]), p(t["quant_fp"]), p(t["quant_shift"]), p(q1), p(d1), p(t["dequant"]), C.byref(e1), p(scan), p(iscan))
+                    if use_qm:
+                        getattr(leaf, "svt_av1_highbd_quantize_fp_qm_hip" if hbd else "svt_av1_quantize_fp_qm_hip")(*common, m, im, C.c_int16(log_scale))
+                    elif hbd:
+                        leaf.svt_av1_highbd_quantize_fp_hip(*common, C.c_int16(log_scale))
+                    else:
+                        getattr(leaf, ("svt_av1_quantize_fp_hip", "svt_av1_quantize_fp_32x32_hip", "svt_av1_quantize_fp_64x64_hip")[log_scale])(*common)
+                    oracle.orc_quantize_fp(p(co), C.c_ssize_t(n), p(t["round_fp"]), p(t["quant_fp"]), p(q2), p(d2), p(t["dequant"]), C.byref(e2), p(scan), m, im, log_scale, hbd)
+                    assert e1.value == e2.value and np.array_equal(q1, q2) and np.array_equal(d1, d2), ("fp", hbd, case, pat, use_qm)
