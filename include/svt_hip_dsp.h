@@ -74,6 +74,24 @@ typedef struct SvtHipRdBatchDesc {
  * Returns non-zero (and leaves nothing enqueued) when the descriptor fails validation. */
 int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d);
 
+/* ---- inverse transform + reconstruction alone ------------------------------------------------------------------
+ * The tail of the RD chain on caller-supplied dequantized coefficients: svt_av1_inv_txfm2d_add_{W}x{H} (Codec/inv_transforms.c:
+ * 2459-2716) = recon = clip(pred + inverse(dqcoeff)), read and write planes separate (may alias), as svt_aom_inv_transform_recon /
+ * svt_aom_inv_transform_recon8bit drive it in the encode pass (inv_transforms.c:3087-3192). */
+typedef struct SvtHipInvTxBatchDesc {
+    uint8_t  bit_depth;    /* 8 or 10: clamp ranges of the stages and of the output */
+    uint8_t  sample_bytes; /* 1: uint8 planes (bit_depth 8 only); 2: uint16 planes (the `_c` entries' layout for either depth) */
+    uint8_t  tx_size;      /* shared by the batch */
+    uint8_t  reserved;
+    uint32_t n_jobs;
+    uint32_t pred_stride, recon_stride; /* in samples */
+    const void        *pred;            /* device pointers */
+    void              *recon;
+    const SvtHipTxJob *jobs;            /* pred_offset: the block in `pred`; src_offset: the block in `recon`; tx_type */
+    const int32_t     *dqcoeff;         /* [n_jobs][min(W,32) * min(H,32)] packed like the reference's inverse entries take them */
+} SvtHipInvTxBatchDesc;
+int svt_hip_inv_txfm_batch(SvtHipContext *ctx, const SvtHipInvTxBatchDesc *d);
+
 /* ---- batched block statistics ---------------------------------------------------------------------------------
  * Per job: SAD, SSE, variance and Hadamard SATD of (src block - ref block).  Restates
  *   svt_nxm_sad_kernel_helper_c / svt_aom_sad_16b_kernel_c          (C_DEFAULT/compute_sad_c.c:20-56,209)

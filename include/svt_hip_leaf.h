@@ -90,6 +90,19 @@ void svt_av1_highbd_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coef
                                        const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
                                        const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
 
+/* svt_av1_inv_txfm2d_add_{W}x{H} (common_dsp_rtcd.h:100-141; Codec/inv_transforms.c:2459-2716): uint16 planes, bd 8 or 10, the three prototype
+ * forms of the reference (squares; rectangles with tx_size + eob; the 4-wide / 4-high ones with tx_size).  TxType / TxSize are one-byte enums. */
+#define SVT_HIP_DECL_INV_SQ(W, H) void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, int32_t bd);
+SVT_HIP_DECL_INV_SQ(4, 4) SVT_HIP_DECL_INV_SQ(8, 8) SVT_HIP_DECL_INV_SQ(16, 16) SVT_HIP_DECL_INV_SQ(32, 32) SVT_HIP_DECL_INV_SQ(64, 64)
+#undef SVT_HIP_DECL_INV_SQ
+#define SVT_HIP_DECL_INV_RECT(W, H) void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, uint8_t tx_size, int32_t eob, int32_t bd);
+SVT_HIP_DECL_INV_RECT(8, 16) SVT_HIP_DECL_INV_RECT(16, 8) SVT_HIP_DECL_INV_RECT(16, 32) SVT_HIP_DECL_INV_RECT(32, 16) SVT_HIP_DECL_INV_RECT(32, 64)
+SVT_HIP_DECL_INV_RECT(64, 32) SVT_HIP_DECL_INV_RECT(8, 32) SVT_HIP_DECL_INV_RECT(32, 8) SVT_HIP_DECL_INV_RECT(16, 64) SVT_HIP_DECL_INV_RECT(64, 16)
+#undef SVT_HIP_DECL_INV_RECT
+#define SVT_HIP_DECL_INV_SMALL(W, H) void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, uint8_t tx_size, int32_t bd);
+SVT_HIP_DECL_INV_SMALL(4, 8) SVT_HIP_DECL_INV_SMALL(8, 4) SVT_HIP_DECL_INV_SMALL(4, 16) SVT_HIP_DECL_INV_SMALL(16, 4)
+#undef SVT_HIP_DECL_INV_SMALL
+
 /* svt_aom_sse (aom_dsp_rtcd.h:53), svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (common_dsp_rtcd.h:164-168) */
 int64_t  svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height);
 uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,

@@ -94,6 +94,13 @@ class MeResults(C.Structure):
     ]
 
 
+class InvTxBatchDesc(C.Structure):
+    """SvtHipInvTxBatchDesc (include/svt_hip_dsp.h)."""
+    _fields_ = [("bit_depth", C.c_uint8), ("sample_bytes", C.c_uint8), ("tx_size", C.c_uint8), ("reserved", C.c_uint8), ("n_jobs", C.c_uint32),
+                ("pred_stride", C.c_uint32), ("recon_stride", C.c_uint32), ("pred", C.c_void_p), ("recon", C.c_void_p), ("jobs", C.c_void_p),
+                ("dqcoeff", C.c_void_p)]
+
+
 class PredJob(C.Structure):
     """SvtHipPredJob (include/svt_hip_dsp.h)."""
     _fields_ = [("ref", C.c_void_p), ("sb_best_mv", C.c_void_p), ("pred", C.c_void_p), ("b64_row_start", C.c_uint32), ("b64_row_count", C.c_uint32),

@@ -584,6 +584,80 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Inverse transform + reconstruction alone (inv_txfm2d_add_c, inv_transforms.c:2459-2535; svt_av1_inv_txfm2d_add_{W}x{H}_c
+// :2545-2716): the tail of rd_tx_kernel fed with caller-supplied dequantized coefficients (packed min(W,32) x min(H,32), as
+// the reference's own inverse entries take them).  Same wave layout and LDS use as rd_tx_kernel.
+// ---------------------------------------------------------------------------------------------------------
+struct InvParams {
+    SvtHipInvTxBatchDesc d;
+};
+template <int TS, int BD, typename Pix> __global__ void __launch_bounds__(64, rd_waves_per_simd(TS)) inv_tx_kernel(const InvParams p) {
+    constexpr int W = tx_wide(TS), H = tx_high(TS), WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
+    constexpr int LW = rd_lanes_per_block(TS), BPW = rd_blocks_per_wave(TS);
+    constexpr int PA = W + 1, PB = WP + 1;
+    constexpr int ROW_CLAMP = BD == 8 ? 16 : 18, COL_CLAMP = 16;
+    constexpr bool RECT = (W == 2 * H || H == 2 * W);
+    __shared__ int32_t lds[BPW][H * PA];
+    const int      lane = threadIdx.x, blk = lane / LW, l = lane % LW;
+    const uint32_t job   = blockIdx.x * BPW + blk;
+    const bool     valid = job < p.d.n_jobs;
+    int32_t *A = lds[blk];
+    const SvtHipTxJob jb = p.d.jobs[valid ? job : 0];
+    const int tt = jb.tx_type & 15, vt = c_vtx[tt], ht = c_htx[tt];
+    const bool ud = (vt == 2), lr = (ht == 2);
+    const Pix *pred = static_cast<const Pix *>(p.d.pred) + jb.pred_offset;
+    const int32_t *dq = p.d.dqcoeff + (size_t)(valid ? job : 0) * NP;
+    for (int rc = l; rc < NP; rc += LW) { const int r = rc / WP, c = rc - r * WP; A[r * PB + c] = dq[rc]; }
+    __syncthreads();
+    if (l < H) { // inverse rows (:2497-2511)
+        int32_t x[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int32_t v = (l < HP && c < WP) ? A[l * PB + c] : 0;
+            if constexpr (RECT) v = rshift64((i64)v * 2896, 12);
+            x[c] = clampv(v, BD + 8);
+        }
+        inv_1d<W, ROW_CLAMP>(x, ht);
+        shift_vec<W>(x, c_inv_shift0[TS]);
+#pragma unroll
+        for (int c = 0; c < W; c++) A[l * PA + c] = x[c];
+    }
+    __syncthreads();
+    if (l < W) { // inverse columns (:2513-2534)
+        int32_t x[H];
+        const int ic = lr ? W - 1 - l : l;
+#pragma unroll
+        for (int r = 0; r < H; r++) x[r] = (r < HP) ? clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16) : 0;
+        inv_1d<H, COL_CLAMP>(x, vt);
+        shift_vec<H>(x, -4);
+#pragma unroll
+        for (int r = 0; r < H; r++) A[r * PA + l] = x[ud ? H - 1 - r : r];
+    }
+    __syncthreads();
+    if (valid) {
+        Pix *rec = static_cast<Pix *>(p.d.recon) + jb.src_offset;
+        for (int i = l; i < W * H; i += LW) {
+            const int r = i / W, c = i - r * W;
+            int v = (int)pred[(size_t)r * p.d.pred_stride + c] + A[r * PA + c];
+            v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
+            rec[(size_t)r * p.d.recon_stride + c] = (Pix)v;
+        }
+    }
+}
+
+template <int BD, typename Pix> int launch_inv(SvtHipContext *ctx, const InvParams &p) {
+    const dim3 b(64);
+#define CASE(S) case S: hipLaunchKernelGGL((inv_tx_kernel<S, BD, Pix>), dim3((p.d.n_jobs + rd_blocks_per_wave(S) - 1) / rd_blocks_per_wave(S)), b, 0, ctx->stream, p); break;
+    switch (p.d.tx_size) {
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+    default: return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %d", p.d.tx_size);
+    }
+#undef CASE
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
 template <int BD> int launch_size(SvtHipContext *ctx, const RdParams &p) {
     const dim3 b(64);
 #define CASE(S) case S: hipLaunchKernelGGL((rd_tx_kernel<S, BD>), dim3((p.d.n_jobs + rd_blocks_per_wave(S) - 1) / rd_blocks_per_wave(S)), b, 0, ctx->stream, p); break;
@@ -772,4 +846,19 @@ extern "C" int svt_hip_fullpel_pred_batch(SvtHipContext *ctx, uint32_t ref_strid
     else hipLaunchKernelGGL(fullpel_pred_batch_kernel<uint16_t>, g, blk, 0, ctx->stream, pb, ref_stride, (int)width, (int)height, w64, pred_stride, vec_ok);
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_inv_txfm_batch(SvtHipContext *ctx, const SvtHipInvTxBatchDesc *d) {
+    if (!ctx || !d) return SVT_HIP_ERR_BAD_PARAM;
+    if (d->n_jobs == 0) return SVT_HIP_OK;
+    if ((d->bit_depth != 8 && d->bit_depth != 10) || (d->sample_bytes != 1 && d->sample_bytes != 2) || (d->bit_depth == 10 && d->sample_bytes != 2))
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "inverse batch: bit_depth %u with %u-byte samples", d->bit_depth, d->sample_bytes);
+    if (d->tx_size >= SVT_HIP_TX_SIZES_ALL) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %u", d->tx_size);
+    if (!d->pred || !d->recon || !d->jobs || !d->dqcoeff) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a pointer of the inverse batch is null");
+    hipSetDevice(ctx->device);
+    if (int rc = init_tables(ctx)) return rc;
+    InvParams p;
+    p.d = *d;
+    if (d->bit_depth == 10) return launch_inv<10, uint16_t>(ctx, p);
+    return d->sample_bytes == 1 ? launch_inv<8, uint8_t>(ctx, p) : launch_inv<8, uint16_t>(ctx, p);
 }

@@ -1124,3 +1124,64 @@ void svt_av1_highbd_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coef
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// svt_av1_inv_txfm2d_add_{W}x{H} (common_dsp_rtcd.h:100-141; bodies Codec/inv_transforms.c:2459-2716) as pointer-level
+// entries: uint16 planes for either bit depth, separate read / write pointers, packed coefficients for the 64-point sizes.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+void leaf_inv_txfm(const int32_t *input, const uint16_t *out_r, int32_t stride_r, uint16_t *out_w, int32_t stride_w, int tx_type, int tx_size, int bd) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    if ((bd != 8 && bd != 10) || tx_size < 0 || tx_size >= SVT_HIP_TX_SIZES_ALL || tx_type < 0 || tx_type >= SVT_HIP_TX_TYPES || stride_r <= 0 || stride_w <= 0) {
+        fprintf(stderr, "libsvthip: svt_av1_inv_txfm2d_add_hip: unsupported bd %d / tx_size %d / tx_type %d\n", bd, tx_size, tx_type);
+        abort();
+    }
+    const int W = svt_hip_tx_size_wide(tx_size), H = svt_hip_tx_size_high(tx_size), NP = (W > 32 ? 32 : W) * (H > 32 ? 32 : H);
+    const size_t cb = align256((size_t)NP * 4), rbytes = (((size_t)H - 1) * stride_r + W) * 2, wbytes = (size_t)W * H * 2;
+    uint8_t *base = leaf_scratch(ctx, cb + align256(rbytes) + align256(wbytes) + 256);
+    uint8_t *d_co = base, *d_pred = d_co + cb, *d_rec = d_pred + align256(rbytes), *d_job = d_rec + align256(wbytes);
+    leaf_check(ctx, hipMemcpyAsync(d_co, input, (size_t)NP * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_pred, out_r, rbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    SvtHipTxJob job;
+    memset(&job, 0, sizeof(job));
+    job.tx_type = (uint8_t)tx_type;
+    leaf_check(ctx, hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    SvtHipInvTxBatchDesc d;
+    memset(&d, 0, sizeof(d));
+    d.bit_depth = (uint8_t)bd; d.sample_bytes = 2; d.tx_size = (uint8_t)tx_size; d.n_jobs = 1; d.pred_stride = (uint32_t)stride_r; d.recon_stride = (uint32_t)W;
+    d.pred = d_pred; d.recon = d_rec; d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.dqcoeff = reinterpret_cast<const int32_t *>(d_co);
+    if (svt_hip_inv_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    leaf_check(ctx, hipMemcpy2DAsync(out_w, (size_t)stride_w * 2, d_rec, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy2DAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+} // namespace
+
+extern "C" {
+// TxType and TxSize are one-byte (ATTRIBUTE_PACKED) enums in the reference (definitions.h): uint8_t is the same ABI
+#define SVT_HIP_INV_SQ(W, H, TS)                                                                                                                       \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, \
+                                                int32_t bd) {                                                                                         \
+        leaf_inv_txfm(input, output_r, stride_r, output_w, stride_w, tx_type, TS, bd);                                                                \
+    }
+SVT_HIP_INV_SQ(4, 4, 0) SVT_HIP_INV_SQ(8, 8, 1) SVT_HIP_INV_SQ(16, 16, 2) SVT_HIP_INV_SQ(32, 32, 3) SVT_HIP_INV_SQ(64, 64, 4)
+#undef SVT_HIP_INV_SQ
+#define SVT_HIP_INV_RECT(W, H, TS)                                                                                                                     \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, \
+                                                uint8_t tx_size, int32_t eob, int32_t bd) {                                                           \
+        (void)tx_size; (void)eob; /* eob only lets the reference skip zero rows; the result does not depend on it */                                  \
+        leaf_inv_txfm(input, output_r, stride_r, output_w, stride_w, tx_type, TS, bd);                                                                \
+    }
+SVT_HIP_INV_RECT(8, 16, 7) SVT_HIP_INV_RECT(16, 8, 8) SVT_HIP_INV_RECT(16, 32, 9) SVT_HIP_INV_RECT(32, 16, 10) SVT_HIP_INV_RECT(32, 64, 11) SVT_HIP_INV_RECT(64, 32, 12)
+SVT_HIP_INV_RECT(8, 32, 15) SVT_HIP_INV_RECT(32, 8, 16) SVT_HIP_INV_RECT(16, 64, 17) SVT_HIP_INV_RECT(64, 16, 18)
+#undef SVT_HIP_INV_RECT
+#define SVT_HIP_INV_SMALL(W, H, TS)                                                                                                                    \
+    void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, \
+                                                uint8_t tx_size, int32_t bd) {                                                                        \
+        (void)tx_size;                                                                                                                                \
+        leaf_inv_txfm(input, output_r, stride_r, output_w, stride_w, tx_type, TS, bd);                                                                \
+    }
+SVT_HIP_INV_SMALL(4, 8, 5) SVT_HIP_INV_SMALL(8, 4, 6) SVT_HIP_INV_SMALL(4, 16, 13) SVT_HIP_INV_SMALL(16, 4, 14)
+#undef SVT_HIP_INV_SMALL
+} // extern "C"

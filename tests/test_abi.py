@@ -38,6 +38,9 @@ def test_library_exports_every_declared_symbol():
              "svt_av1_highbd_quantize_fp_qm_hip"]
     missing = [s for s in quant if not hasattr(L, s)]
     assert not missing, missing
+    from txfm_cases import TX_H, TX_W
+    missing = [f"svt_av1_inv_txfm2d_add_{w}x{h}_hip" for w, h in zip(TX_W, TX_H) if not hasattr(L, f"svt_av1_inv_txfm2d_add_{w}x{h}_hip")]
+    assert not missing, missing
     missing = [f"svt_aom_sad{w}x{h}{k}_hip" for (w, h) in abi.VARIANCE_SIZES for k in ("", "x4d") if not hasattr(L, f"svt_aom_sad{w}x{h}{k}_hip")]
     assert not missing, missing
 

@@ -107,3 +107,84 @@ def test_out_of_range_16bit_samples_stay_exact(hip_ctx, tx_size):
     jobs["tx_type"] = rng.choice(valid_types(tx_size), len(jobs))
     f = dict(bit_depth=10, quant_kind=0, tx_size=tx_size, src_stride=192, pred_stride=192)
     _check(pyoracle.rd_batch(f, src, pred, jobs, rows), rd.run_hip(hip_ctx, f, src, pred, jobs, rows), tx_size)
+
+
+# ---- inverse transform alone: the 19 pointer-level entries and the batched entry ------------------------------------------------
+def _hip_inv_leaf(L, ts, tt, co, pred, stride, out_stride, bd):
+    import ctypes as C
+    from txfm_cases import TX_H, TX_W
+    w, h = TX_W[ts], TX_H[ts]
+    out = np.full((h, out_stride), 0x5555, np.uint16)
+    a = [co.ctypes.data_as(C.c_void_p), pred.ctypes.data_as(C.c_void_p), C.c_int32(stride), out.ctypes.data_as(C.c_void_p), C.c_int32(out_stride), C.c_uint8(tt)]
+    if w == h:
+        a += [C.c_int32(bd)]
+    elif (w, h) in ((4, 8), (8, 4), (4, 16), (16, 4)):
+        a += [C.c_uint8(ts), C.c_int32(bd)]
+    else:
+        a += [C.c_uint8(ts), C.c_int32(w * h), C.c_int32(bd)]
+    getattr(L, f"svt_av1_inv_txfm2d_add_{w}x{h}_hip")(*a)
+    return out
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+def test_leaf_inverse_transforms(hip_ctx, oracle, tx_size):
+    """svt_av1_inv_txfm2d_add_{W}x{H}_hip: every allowed type, 8 / 10 bit, random and extreme coefficients, separate read / write planes."""
+    import ctypes as C
+    from svt_av1_psyex_amd import api
+    from txfm_cases import TX_H, TX_W, valid_types
+    L = api.lib()
+    assert L.svt_hip_leaf_bind(hip_ctx._h) == 0
+    try:
+        rng = np.random.default_rng(300 + tx_size)
+        w, h = TX_W[tx_size], TX_H[tx_size]
+        n = min(w, 32) * min(h, 32)
+        for tt in valid_types(tx_size):
+            for bd, pat in [(8, "random"), (10, "random"), (10, "big"), (8, "sparse")]:
+                stride, ostride = w + int(rng.integers(0, 5)), w + int(rng.integers(0, 3))
+                co = {"random": rng.integers(-(1 << (bd + 7)), 1 << (bd + 7), n), "big": rng.choice([-(1 << 17), (1 << 17) - 1, 0], n),
+                      "sparse": np.where(rng.random(n) < 0.05, rng.integers(-3000, 3000, n), 0)}[pat].astype(np.int32)
+                pred = rng.integers(0, 1 << bd, (h, stride)).astype(np.uint16)
+                want = np.full((h, ostride), 0x5555, np.uint16)
+                oracle.orc_inv_txfm2d_add(co.ctypes.data_as(C.c_void_p), pred.ctypes.data_as(C.c_void_p), C.c_int32(stride), want.ctypes.data_as(C.c_void_p),
+                                          C.c_int32(ostride), tt, tx_size, bd)
+                got = _hip_inv_leaf(L, tx_size, tt, co, pred, stride, ostride, bd)
+                assert np.array_equal(got, want), (tt, bd, pat)
+    finally:
+        L.svt_hip_leaf_bind(None)
+
+
+@pytest.mark.parametrize("tx_size,bd,sample_bytes", [(2, 10, 2), (3, 8, 1), (4, 10, 2), (9, 8, 2), (12, 10, 2), (0, 8, 1)])
+def test_inverse_batch_matches_oracle(hip_ctx, oracle, tx_size, bd, sample_bytes):
+    """svt_hip_inv_txfm_batch: a plane's worth of blocks in one launch, read plane != write plane, uint8 and uint16 storage."""
+    import ctypes as C
+    import torch
+    from svt_av1_psyex_amd import abi, api, rd
+    from txfm_cases import TX_H, TX_W, valid_types
+    rng = np.random.default_rng(900 + tx_size)
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    n = min(w, 32) * min(h, 32)
+    PW, PH = 192, 128
+    jobs = rd.grid_jobs(PW, PH, PW, tx_size)
+    types = valid_types(tx_size)
+    jobs["tx_type"] = rng.choice(types, len(jobs))
+    dt = np.uint8 if sample_bytes == 1 else np.uint16
+    pred = rng.integers(0, 1 << bd, (PH, PW)).astype(dt)
+    co = np.where(rng.random((len(jobs), n)) < 0.3, rng.integers(-(1 << (bd + 6)), 1 << (bd + 6), (len(jobs), n)), 0).astype(np.int32)
+    want = np.zeros((PH, PW), np.uint16)
+    p16 = pred.astype(np.uint16)
+    for j, jb in enumerate(jobs):
+        off = int(jb["pred_offset"])
+        oracle.orc_inv_txfm2d_add(C.c_void_p(co[j].ctypes.data), C.c_void_p(p16.ctypes.data + 2 * off), C.c_int32(PW), C.c_void_p(want.ctypes.data + 2 * off),
+                                  C.c_int32(PW), int(jb["tx_type"]), tx_size, bd)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+    t_pred, t_co, t_jobs = dev(pred), dev(co), dev(jobs)
+    t_rec = torch.zeros(PH * PW * sample_bytes, dtype=torch.uint8, device="cuda")
+    d = abi.InvTxBatchDesc(bit_depth=bd, sample_bytes=sample_bytes, tx_size=tx_size, n_jobs=len(jobs), pred_stride=PW, recon_stride=PW, pred=t_pred.data_ptr(),
+                           recon=t_rec.data_ptr(), jobs=t_jobs.data_ptr(), dqcoeff=t_co.data_ptr())
+    torch.cuda.synchronize()
+    hip_ctx.check(api.lib().svt_hip_inv_txfm_batch(hip_ctx._h, C.byref(d)), "svt_hip_inv_txfm_batch")
+    hip_ctx.sync()
+    got = t_rec.cpu().numpy().view(dt).reshape(PH, PW)
+    assert np.array_equal(got.astype(np.uint16), want)
+    d.sample_bytes = 1 if bd == 10 else 3
+    assert api.lib().svt_hip_inv_txfm_batch(hip_ctx._h, C.byref(d)) == 2
