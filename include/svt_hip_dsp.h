@@ -74,6 +74,19 @@ typedef struct SvtHipRdBatchDesc {
  * Returns non-zero (and leaves nothing enqueued) when the descriptor fails validation. */
 int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d);
 
+/* ---- forward transform alone ------------------------------------------------------------------------------------
+ * svt_av1_fwd_txfm2d_{W}x{H}{,_N2,_N4} (Codec/transforms.c:2259-2631,5202-5425,6769-6990) on an int16 residual plane: the FULL W x H
+ * coefficient array per job, row-major (what the per-size pointers return; packing the 64-point sizes is svt_handle_transform*). */
+typedef struct SvtHipFwdTxBatchDesc {
+    uint8_t  tx_size, reserved[3];
+    uint32_t n_jobs;
+    uint32_t residual_stride;    /* in samples */
+    const int16_t     *residual; /* device pointers */
+    const SvtHipTxJob *jobs;     /* src_offset: the block in `residual`; tx_type; pf_shape 0 / 1 / 2 = full / _N2 / _N4 */
+    int32_t           *coeff;    /* [n_jobs][W * H] */
+} SvtHipFwdTxBatchDesc;
+int svt_hip_fwd_txfm_batch(SvtHipContext *ctx, const SvtHipFwdTxBatchDesc *d);
+
 /* ---- inverse transform + reconstruction alone ------------------------------------------------------------------
  * The tail of the RD chain on caller-supplied dequantized coefficients: svt_av1_inv_txfm2d_add_{W}x{H} (Codec/inv_transforms.c:
  * 2459-2716) = recon = clip(pred + inverse(dqcoeff)), read and write planes separate (may alias), as svt_aom_inv_transform_recon /

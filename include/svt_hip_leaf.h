@@ -90,6 +90,17 @@ void svt_av1_highbd_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coef
                                        const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
                                        const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale);
 
+/* svt_av1_fwd_txfm2d_{W}x{H}{,_N2,_N4} (aom_dsp_rtcd.c:421-487; Codec/transforms.c:2259-2631,5202-5425,6769-6990): int16 residual ->
+ * the full W x H coefficient array (the _N2 / _N4 entries keep the top-left half / quarter per dimension, zeros elsewhere) */
+#define SVT_HIP_DECL_FWD(W, H)                                                                                            \
+    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd);    \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd); \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd);
+SVT_HIP_DECL_FWD(4, 4) SVT_HIP_DECL_FWD(8, 8) SVT_HIP_DECL_FWD(16, 16) SVT_HIP_DECL_FWD(32, 32) SVT_HIP_DECL_FWD(64, 64) SVT_HIP_DECL_FWD(4, 8) SVT_HIP_DECL_FWD(8, 4)
+SVT_HIP_DECL_FWD(8, 16) SVT_HIP_DECL_FWD(16, 8) SVT_HIP_DECL_FWD(16, 32) SVT_HIP_DECL_FWD(32, 16) SVT_HIP_DECL_FWD(32, 64) SVT_HIP_DECL_FWD(64, 32)
+SVT_HIP_DECL_FWD(4, 16) SVT_HIP_DECL_FWD(16, 4) SVT_HIP_DECL_FWD(8, 32) SVT_HIP_DECL_FWD(32, 8) SVT_HIP_DECL_FWD(16, 64) SVT_HIP_DECL_FWD(64, 16)
+#undef SVT_HIP_DECL_FWD
+
 /* svt_av1_inv_txfm2d_add_{W}x{H} (common_dsp_rtcd.h:100-141; Codec/inv_transforms.c:2459-2716): uint16 planes, bd 8 or 10, the three prototype
  * forms of the reference (squares; rectangles with tx_size + eob; the 4-wide / 4-high ones with tx_size).  TxType / TxSize are one-byte enums. */
 #define SVT_HIP_DECL_INV_SQ(W, H) void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, int32_t bd);

@@ -658,6 +658,78 @@ template <int BD, typename Pix> int launch_inv(SvtHipContext *ctx, const InvPara
     return SVT_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward transform alone (av1_tranform_two_d_core_c, transforms.c:2259-2324; svt_av1_fwd_txfm2d_{W}x{H}{,_N2,_N4}_c): the
+// head of rd_tx_kernel on a caller-supplied int16 residual, writing the FULL W x H coefficient array the per-size pointers
+// return (the 64-point sizes included: packing to 32 x 32 is svt_handle_transform*'s job in the reference, :2374-2505).
+// ---------------------------------------------------------------------------------------------------------
+struct FwdParams {
+    SvtHipFwdTxBatchDesc d;
+};
+template <int TS> __global__ void __launch_bounds__(64, rd_waves_per_simd(TS)) fwd_tx_kernel(const FwdParams p) {
+    constexpr int W = tx_wide(TS), H = tx_high(TS);
+    constexpr int LW = rd_lanes_per_block(TS), BPW = rd_blocks_per_wave(TS);
+    constexpr int PA = W + 1;
+    constexpr bool RECT = (W == 2 * H || H == 2 * W);
+    __shared__ int32_t lds[BPW][H * PA];
+    const int      lane = threadIdx.x, blk = lane / LW, l = lane % LW;
+    const uint32_t job   = blockIdx.x * BPW + blk;
+    const bool     valid = job < p.d.n_jobs;
+    int32_t *A = lds[blk];
+    const SvtHipTxJob jb = p.d.jobs[valid ? job : 0];
+    const int tt = jb.tx_type & 15, vt = c_vtx[tt], ht = c_htx[tt];
+    const bool ud = (vt == 2), lr = (ht == 2);
+    const int16_t *res = p.d.residual + jb.src_offset;
+    const int8_t *fsh = c_fwd_shift[TS];
+    const int bit_col = c_fwd_cos_col[ilog2c(W) - 2][ilog2c(H) - 2], bit_row = c_fwd_cos_row[ilog2c(W) - 2][ilog2c(H) - 2];
+    for (int i = l; i < W * H; i += LW) { const int r = i / W, c = i - r * W; A[r * PA + c] = res[(size_t)r * p.d.residual_stride + c]; }
+    __syncthreads();
+    if (l < W) { // columns (:2287-2308)
+        int32_t x[H];
+#pragma unroll
+        for (int r = 0; r < H; r++) x[r] = A[(ud ? H - 1 - r : r) * PA + l];
+        shift_vec<H>(x, fsh[0]);
+        fwd_1d<H>(x, vt, bit_col);
+        shift_vec<H>(x, fsh[1]);
+        const int oc = lr ? W - 1 - l : l;
+#pragma unroll
+        for (int r = 0; r < H; r++) A[r * PA + oc] = x[r];
+    }
+    __syncthreads();
+    if (l < H) { // rows (:2310-2323)
+        int32_t x[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) x[c] = A[l * PA + c];
+        fwd_1d<W>(x, ht, bit_row);
+        shift_vec<W>(x, fsh[2]);
+        if constexpr (RECT) {
+#pragma unroll
+            for (int c = 0; c < W; c++) x[c] = rshift64((i64)x[c] * 5793, 12);
+        }
+#pragma unroll
+        for (int c = 0; c < W; c++) A[l * PA + c] = x[c];
+    }
+    __syncthreads();
+    if (valid) { // the partial-frequency entries (_N2 / _N4, transforms.c:5202-5425,6769-6990) keep the top-left half / quarter and store zeros elsewhere
+        const int pf = jb.pf_shape & 3;
+        const int keep_w = pf == 3 ? 1 : (W >> pf), keep_h = pf == 3 ? 1 : (H >> pf);
+        int32_t *out = p.d.coeff + (size_t)job * W * H;
+        for (int i = l; i < W * H; i += LW) { const int r = i / W, c = i - r * W; out[i] = (c < keep_w && r < keep_h) ? A[r * PA + c] : 0; }
+    }
+}
+
+int launch_fwd(SvtHipContext *ctx, const FwdParams &p) {
+    const dim3 b(64);
+#define CASE(S) case S: hipLaunchKernelGGL((fwd_tx_kernel<S>), dim3((p.d.n_jobs + rd_blocks_per_wave(S) - 1) / rd_blocks_per_wave(S)), b, 0, ctx->stream, p); break;
+    switch (p.d.tx_size) {
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+    default: return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %d", p.d.tx_size);
+    }
+#undef CASE
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
 template <int BD> int launch_size(SvtHipContext *ctx, const RdParams &p) {
     const dim3 b(64);
 #define CASE(S) case S: hipLaunchKernelGGL((rd_tx_kernel<S, BD>), dim3((p.d.n_jobs + rd_blocks_per_wave(S) - 1) / rd_blocks_per_wave(S)), b, 0, ctx->stream, p); break;
@@ -861,4 +933,16 @@ extern "C" int svt_hip_inv_txfm_batch(SvtHipContext *ctx, const SvtHipInvTxBatch
     p.d = *d;
     if (d->bit_depth == 10) return launch_inv<10, uint16_t>(ctx, p);
     return d->sample_bytes == 1 ? launch_inv<8, uint8_t>(ctx, p) : launch_inv<8, uint16_t>(ctx, p);
+}
+
+extern "C" int svt_hip_fwd_txfm_batch(SvtHipContext *ctx, const SvtHipFwdTxBatchDesc *d) {
+    if (!ctx || !d) return SVT_HIP_ERR_BAD_PARAM;
+    if (d->n_jobs == 0) return SVT_HIP_OK;
+    if (d->tx_size >= SVT_HIP_TX_SIZES_ALL) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %u", d->tx_size);
+    if (!d->residual || !d->jobs || !d->coeff) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a pointer of the forward batch is null");
+    hipSetDevice(ctx->device);
+    if (int rc = init_tables(ctx)) return rc;
+    FwdParams p;
+    p.d = *d;
+    return launch_fwd(ctx, p);
 }

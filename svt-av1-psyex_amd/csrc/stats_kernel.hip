@@ -1185,3 +1185,49 @@ SVT_HIP_INV_RECT(8, 32, 15) SVT_HIP_INV_RECT(32, 8, 16) SVT_HIP_INV_RECT(16, 64,
 SVT_HIP_INV_SMALL(4, 8, 5) SVT_HIP_INV_SMALL(8, 4, 6) SVT_HIP_INV_SMALL(4, 16, 13) SVT_HIP_INV_SMALL(16, 4, 14)
 #undef SVT_HIP_INV_SMALL
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// svt_av1_fwd_txfm2d_{W}x{H}{,_N2,_N4} (aom_dsp_rtcd.h / aom_dsp_rtcd.c:421-487; bodies Codec/transforms.c) as pointer-level
+// entries: the full W x H coefficient array, like the reference's per-size pointers (bd only selects stage ranges there).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+void leaf_fwd_txfm(const int16_t *input, int32_t *output, uint32_t stride, int tx_type, int tx_size, int pf_shape) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    if (tx_type < 0 || tx_type >= SVT_HIP_TX_TYPES) { fprintf(stderr, "libsvthip: svt_av1_fwd_txfm2d_hip: tx_type %d\n", tx_type); abort(); }
+    const int W = svt_hip_tx_size_wide(tx_size), H = svt_hip_tx_size_high(tx_size);
+    const size_t rbytes = (((size_t)H - 1) * stride + W) * 2, obytes = (size_t)W * H * 4;
+    uint8_t *base = leaf_scratch(ctx, align256(rbytes) + align256(obytes) + 256);
+    uint8_t *d_res = base, *d_out = d_res + align256(rbytes), *d_job = d_out + align256(obytes);
+    leaf_check(ctx, hipMemcpyAsync(d_res, input, rbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    SvtHipTxJob job;
+    memset(&job, 0, sizeof(job));
+    job.tx_type = (uint8_t)tx_type; job.pf_shape = (uint8_t)pf_shape;
+    leaf_check(ctx, hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    SvtHipFwdTxBatchDesc d;
+    memset(&d, 0, sizeof(d));
+    d.tx_size = (uint8_t)tx_size; d.n_jobs = 1; d.residual_stride = stride; d.residual = reinterpret_cast<const int16_t *>(d_res);
+    d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.coeff = reinterpret_cast<int32_t *>(d_out);
+    if (svt_hip_fwd_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    leaf_check(ctx, hipMemcpyAsync(output, d_out, obytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+} // namespace
+
+extern "C" {
+#define SVT_HIP_FWD(W, H, TS)                                                                                                                   \
+    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                   \
+        (void)bd; leaf_fwd_txfm(input, output, stride, tx_type, TS, 0);                                                                         \
+    }                                                                                                                                           \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                \
+        (void)bd; leaf_fwd_txfm(input, output, stride, tx_type, TS, 1);                                                                         \
+    }                                                                                                                                           \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                \
+        (void)bd; leaf_fwd_txfm(input, output, stride, tx_type, TS, 2);                                                                         \
+    }
+SVT_HIP_FWD(4, 4, 0) SVT_HIP_FWD(8, 8, 1) SVT_HIP_FWD(16, 16, 2) SVT_HIP_FWD(32, 32, 3) SVT_HIP_FWD(64, 64, 4) SVT_HIP_FWD(4, 8, 5) SVT_HIP_FWD(8, 4, 6)
+SVT_HIP_FWD(8, 16, 7) SVT_HIP_FWD(16, 8, 8) SVT_HIP_FWD(16, 32, 9) SVT_HIP_FWD(32, 16, 10) SVT_HIP_FWD(32, 64, 11) SVT_HIP_FWD(64, 32, 12) SVT_HIP_FWD(4, 16, 13)
+SVT_HIP_FWD(16, 4, 14) SVT_HIP_FWD(8, 32, 15) SVT_HIP_FWD(32, 8, 16) SVT_HIP_FWD(16, 64, 17) SVT_HIP_FWD(64, 16, 18)
+#undef SVT_HIP_FWD
+} // extern "C"

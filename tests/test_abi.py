@@ -41,6 +41,8 @@ def test_library_exports_every_declared_symbol():
     from txfm_cases import TX_H, TX_W
     missing = [f"svt_av1_inv_txfm2d_add_{w}x{h}_hip" for w, h in zip(TX_W, TX_H) if not hasattr(L, f"svt_av1_inv_txfm2d_add_{w}x{h}_hip")]
     assert not missing, missing
+    missing = [f"svt_av1_fwd_txfm2d_{w}x{h}{k}_hip" for w, h in zip(TX_W, TX_H) for k in ("", "_N2", "_N4") if not hasattr(L, f"svt_av1_fwd_txfm2d_{w}x{h}{k}_hip")]
+    assert not missing, missing
     missing = [f"svt_aom_sad{w}x{h}{k}_hip" for (w, h) in abi.VARIANCE_SIZES for k in ("", "x4d") if not hasattr(L, f"svt_aom_sad{w}x{h}{k}_hip")]
     assert not missing, missing
 

@@ -188,3 +188,32 @@ def test_inverse_batch_matches_oracle(hip_ctx, oracle, tx_size, bd, sample_bytes
     assert np.array_equal(got.astype(np.uint16), want)
     d.sample_bytes = 1 if bd == 10 else 3
     assert api.lib().svt_hip_inv_txfm_batch(hip_ctx._h, C.byref(d)) == 2
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+def test_leaf_forward_transforms(hip_ctx, oracle, tx_size):
+    """svt_av1_fwd_txfm2d_{W}x{H}{,_N2,_N4}_hip: the full W x H array (64-point sizes included), every allowed type, the
+    reference's residual patterns (FwdTxfm2dAsmTest.cc: random / extremes)."""
+    import ctypes as C
+    from svt_av1_psyex_amd import api
+    from txfm_cases import TX_H, TX_W, residual_block, valid_types
+    L = api.lib()
+    assert L.svt_hip_leaf_bind(hip_ctx._h) == 0
+    try:
+        rng = np.random.default_rng(700 + tx_size)
+        w, h = TX_W[tx_size], TX_H[tx_size]
+        for tt in valid_types(tx_size):
+            for bd, pat in [(8, "random"), (10, "max"), (10, "checker"), (10, "laplace")]:
+                stride = w + int(rng.integers(0, 5))
+                r = residual_block(rng, w, h, stride, bd, pat)
+                full = np.zeros(w * h, np.int32)
+                oracle.orc_fwd_txfm2d(r.ctypes.data_as(C.c_void_p), full.ctypes.data_as(C.c_void_p), C.c_uint32(stride), tt, tx_size)
+                for suf, sh in (("", 0), ("_N2", 1), ("_N4", 2)):
+                    got = np.full(w * h, 12345, np.int32)
+                    getattr(L, f"svt_av1_fwd_txfm2d_{w}x{h}{suf}_hip")(r.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_uint32(stride), C.c_uint8(tt), C.c_uint8(bd))
+                    want = full.reshape(h, w).copy()
+                    want[h >> sh:, :] = 0
+                    want[:, w >> sh:] = 0
+                    assert np.array_equal(got, want.reshape(-1)), (tt, bd, pat, suf)
+    finally:
+        L.svt_hip_leaf_bind(None)
