@@ -686,6 +686,29 @@ static void fullpel_search(MeState *s, int li, int ri, const uint8_t *win, uint3
 }
 
 /* integer_search_b64: Codec/motion_estimation.c:1249-1516 */
+/* The 64x64 block displaced to (x .. x + w - 1 + 63, y .. y + h - 1 + 63) in picture coordinates.  The reference forms
+ * this address without a bounds check, and its 1-point probe (:1391-1406) uses the UNCLIPPED search centre: a centre far outside
+ * the picture (e.g. the mirrored list-1 pre-HME vector of check_prehme_early_exit, :1693-1720, with HME levels 1 / 2 off) makes
+ * the reference read past its padded plane -- undefined there.  This restatement (and the HIP kernel) define that case: samples
+ * outside the padded plane are those of its nearest edge.  Returns `direct` when the window lies inside the plane, else fills
+ * *tmp (caller frees) and sets *stride. */
+static const uint8_t *window_or_clamped(const SvtHipPlaneDesc *rp, int x, int y, int w, int h, uint8_t **tmp, uint32_t *stride) {
+    const int x0 = -(int)rp->org_x, x1 = (int)rp->width + rp->org_x - 1, y0 = -(int)rp->org_y, y1 = (int)rp->height + rp->org_y - 1;
+    const int ww = w - 1 + 64, hh = h - 1 + 64;
+    *tmp    = NULL;
+    *stride = rp->stride_y;
+    if (x >= x0 && x + ww - 1 <= x1 && y >= y0 && y + hh - 1 <= y1)
+        return rp->buffer_y + ((int64_t)rp->org_x + x) + ((int64_t)rp->org_y + y) * rp->stride_y;
+    *tmp = (uint8_t *)malloc((size_t)ww * hh);
+    for (int r = 0; r < hh; r++)
+        for (int c = 0; c < ww; c++) {
+            const int cx = ORC_MIN(ORC_MAX(x + c, x0), x1), cy = ORC_MIN(ORC_MAX(y + r, y0), y1);
+            (*tmp)[(size_t)r * ww + c] = rp->buffer_y[((int64_t)rp->org_x + cx) + ((int64_t)rp->org_y + cy) * rp->stride_y];
+        }
+    *stride = (uint32_t)ww;
+    return *tmp;
+}
+
 static void integer_search(MeState *s) {
     const SvtHipMeConfig *c = s->cfg;
     const int pic_w = (int16_t)s->pic->aligned_width, pic_h = (int16_t)s->pic->aligned_height;
@@ -728,9 +751,12 @@ static void integer_search(MeState *s) {
                 }
             }
             orc_initialize_buffer_32bits(s->best_sad[li][ri], 21, 1, SVT_HIP_MAX_SAD_VALUE);
-            const uint8_t *pix0 = rp->buffer_y + ((int64_t)rp->org_x + org_x) + ((int64_t)rp->org_y + org_y) * rp->stride_y;
+            uint8_t *tmp;
+            uint32_t wstride;
             if (c->me_8x8_var_enabled && sa_w * sa_h > 24) {
-                fullpel_search(s, li, ri, pix0 + cx + (int64_t)cy * rp->stride_y, rp->stride_y, cx, cy, 1, 1);
+                const uint8_t *win = window_or_clamped(rp, org_x + cx, org_y + cy, 1, 1, &tmp, &wstride);
+                fullpel_search(s, li, ri, win, wstride, cx, cy, 1, 1);
+                free(tmp);
                 const uint32_t *b8   = s->best_sad[li][ri] + 21;
                 const uint32_t  mean = s->best_sad[li][ri][0] / 64;
                 uint32_t        ssq  = 0;
@@ -757,8 +783,9 @@ static void integer_search(MeState *s) {
             clip_axis(org_x, &ox, &w, 63, pic_w);
             w = (w < 8) ? w : (w & ~7);
             clip_axis(org_y, &oy, &h, 63, pic_h);
-            fullpel_search(s, li, ri, pix0 + ox + (int64_t)oy * rp->stride_y, rp->stride_y, (int16_t)ox, (int16_t)oy, (uint32_t)w,
-                           (uint32_t)h);
+            const uint8_t *win = window_or_clamped(rp, org_x + ox, org_y + oy, w, h, &tmp, &wstride);
+            fullpel_search(s, li, ri, win, wstride, (int16_t)ox, (int16_t)oy, (uint32_t)w, (uint32_t)h);
+            free(tmp);
         }
 }
 

@@ -113,6 +113,7 @@ struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_s
     uint32_t       stride;
     int16_t        ox, oy, sa_w, sa_h; // search area origin (MV of index (0,0)) and size
     uint8_t        li, ri, probe, pad;
+    int16_t        min_x, max_x, min_y, max_y; // displacements of pix0 that stay inside the padded plane
 };
 
 struct PreHme {
@@ -661,11 +662,25 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                 const int rows        = h - 1 + 64;
                 const int vec_per_row = pitch >> 4;
                 __syncthreads(); // previous tile fully consumed
-                for (int i = threadIdx.x; i < vec_per_row * rows; i += kThreads) {
-                    const int row = i / vec_per_row, c = i - row * vec_per_row;
-                    typedef uint32_t V4 __attribute__((ext_vector_type(4)));
-                    const V4 v = *reinterpret_cast<const __attribute__((address_space(1))) V4 *>(reinterpret_cast<uintptr_t>(gwin - shift + (long long)row * m.stride + c * 16)); // global, not flat
-                    *reinterpret_cast<V4 *>(&sh.win[row * pitch + c * 16]) = v;
+                // The reference's 1-point probe uses the unclipped search centre (motion_estimation.c:1391-1406): a centre far outside
+                // the picture would take these reads past the padded plane (undefined in the reference; a fault here).  Such a tile
+                // -- uniform test -- is staged sample by sample with coordinates clamped to the plane's edge instead.
+                // (The vector loads of the fast path run up to 15 bytes before and 31 bytes behind the samples they need: the planes
+                // carry that much slack around every row, pictures.hip.)
+                const int wx0 = m.ox + x0 - shift, wy0 = m.oy + y0;
+                if (m.ox + x0 >= m.min_x && m.ox + x0 + w - 1 + 63 <= m.max_x && wy0 >= m.min_y && wy0 + rows - 1 <= m.max_y) {
+                    for (int i = threadIdx.x; i < vec_per_row * rows; i += kThreads) {
+                        const int row = i / vec_per_row, c = i - row * vec_per_row;
+                        typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+                        const V4 v = *reinterpret_cast<const __attribute__((address_space(1))) V4 *>(reinterpret_cast<uintptr_t>(gwin - shift + (long long)row * m.stride + c * 16)); // global, not flat
+                        *reinterpret_cast<V4 *>(&sh.win[row * pitch + c * 16]) = v;
+                    }
+                } else {
+                    for (int i = threadIdx.x; i < pitch * rows; i += kThreads) {
+                        const int row = i / pitch, cb = i - row * pitch;
+                        const int x = imin(imax(wx0 + cb, (int)m.min_x), (int)m.max_x), y = imin(imax(wy0 + row, (int)m.min_y), (int)m.max_y);
+                        sh.win[row * pitch + cb] = m.pix0[x + (long long)y * m.stride];
+                    }
                 }
                 __syncthreads();
                 const int ng = ((shift & 3) + w + 3) >> 2;
@@ -1270,6 +1285,8 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                         }
                         MeReq &m = st.me[st.nme++];
                         m.pix0 = plane_at(rp, (int)st.org_x, (int)st.org_y); m.stride = rp.stride;
+                        m.min_x = (int16_t)(-rp.org_x - (int)st.org_x); m.max_x = (int16_t)(rp.width + rp.org_x - 1 - (int)st.org_x);
+                        m.min_y = (int16_t)(-rp.org_y - (int)st.org_y); m.max_y = (int16_t)(rp.height + rp.org_y - 1 - (int)st.org_y);
                         m.li = (uint8_t)li; m.ri = (uint8_t)ri; m.pad = 0;
                         m.sa_w = sa_w; m.sa_h = sa_h; // provisional size, finalised after the probe
                         m.ox = cx; m.oy = cy;         // the search centre until then

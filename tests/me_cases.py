@@ -91,3 +91,22 @@ MCTF_GRID = [
     dict(width=352, height=288, enc_mode=9, refs={(0, 0): 1, (1, 0): 3}, mctf_exit_th=25000, kind="fastpan"),
     dict(width=352, height=288, enc_mode=2, cur=2, refs={(0, 0): 1, (0, 1): 0, (1, 0): 3, (1, 1): 4}, n_frames=5, mctf_exit_th=100),
 ]
+
+
+def probe_outside_case():
+    """A search centre far outside the picture: list 1 mirrors list 0's pre-HME vector (check_prehme_early_exit,
+    motion_estimation.c:1693-1720), HME levels 1 / 2 are off, so (16, 184) reaches the integer search of the last, 16-px-high b64
+    row of a 144-px-high picture unrefined and the 1-point probe (:1391-1406) addresses rows far below the padded plane.  The
+    reference reads past its buffer there (undefined); oracle and HIP kernel read the plane's nearest edge instead.  Found by
+    tools/me_fuzz_campaign.py (seed 5099)."""
+    def edit(cfg):
+        cfg.hme_search_method = cfg.me_search_method = 1
+        cfg.enable_hme_level1_flag = cfg.enable_hme_level2_flag = 0
+        cfg.prehme_enable = cfg.prehme_skip_search_line = cfg.prehme_l1_early_exit = 1
+        cfg.me_sa.sa_min.width, cfg.me_sa.sa_min.height, cfg.me_sa.sa_max.width, cfg.me_sa.sa_max.height = 8, 37, 136, 37
+        cfg.hme_l0_sa.sa_min.width, cfg.hme_l0_sa.sa_min.height, cfg.hme_l0_sa.sa_max.width, cfg.hme_l0_sa.sa_max.height = 64, 8, 96, 192
+        cfg.me_early_exit_th, cfg.me_8x8_var_enabled, cfg.enable_me_sr_adjustment, cfg.distance_based_hme_resizing = 32768, 1, 1, 0
+        cfg.mv_sa_adj_enabled, cfg.mv_sa_adj_nearest_ref_only, cfg.mv_sa_adj_mv_size_th, cfg.mv_sa_adj_sa_multiplier = 1, 0, 16, 2
+        cfg.prune_ref_if_me_sad_dev_bigger_than_th, cfg.use_best_unipred_cand_only = 0xFFFF, 0
+    return MeCase(640, 144, enc_mode=11, cur=4, refs={(0, 0): 2, (0, 1): 3, (0, 2): 1, (1, 0): 0, (1, 1): 7}, n_frames=9, seed=5099, kind="noise",
+                  temporal_layer_index=1, cfg_edit=edit)

@@ -190,3 +190,15 @@ def api_rc_too_many(ctx, job):
 def test_mctf_matches_oracle(hip_ctx, kw):
     case = MeCase(**kw)
     assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx), MCTF_OUTPUTS)
+
+
+def test_search_centre_outside_the_padded_plane(hip_ctx):
+    """me_cases.probe_outside_case: the reference's 1-point probe would read far below its padded plane (undefined there); the
+    oracle and the kernel both take the plane's nearest edge instead, so they agree, run after run."""
+    from me_cases import probe_outside_case
+    case = probe_outside_case()
+    want = case.run_cpu("oracle")
+    sc = want["hme_sc"].reshape(-1, 2, 4, 2)
+    assert tuple(sc[22, 1, 0]) == (16, 184)  # b64 (2, 2): rows 128..143 of a 144-row picture, centre 184 rows further down
+    for _ in range(3):
+        assert not compare(want, case.run_hip(hip_ctx))

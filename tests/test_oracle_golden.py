@@ -29,3 +29,14 @@ def test_sad_loop_kernel_known_answers(oracle):
                                    C.c_uint8(int(skip)), C.c_int16(int(sw)), C.c_int16(int(sh)))
         assert (b.value, xs.value, ys.value) == (best, x, y), (bw, bh, sw, sh, skip)
     assert so == len(z["src"]) and ro == len(z["ref"])
+
+
+def test_search_centre_outside_the_padded_plane_is_defined(oracle):
+    """The one place where the oracle deliberately leaves the reference (whose read is out of bounds there, see me_cases.probe_outside_case):
+    the result must not depend on what lies behind the plane in memory."""
+    from me_cases import probe_outside_case
+    import numpy as np
+    a = probe_outside_case().run_cpu("oracle")
+    junk = [np.full(1 << 20, v, np.uint8) for v in (0, 255)]  # disturb the heap between the two runs
+    b = probe_outside_case().run_cpu("oracle")
+    assert junk and all(np.array_equal(a[k], b[k]) for k in a)
