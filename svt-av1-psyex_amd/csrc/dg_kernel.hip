@@ -4,7 +4,7 @@
 // Codec/me_process.c:326-331): per b64, an exhaustive svt_sad_loop_kernel search (C_DEFAULT/compute_sad_c.c:58-101) of the
 // 16x16 block of the source's sixteenth plane over a 16 / 64 / 128-squared window of the reference's sixteenth plane, then
 // four picture-level sums.  One workgroup per b64: the window is staged once in LDS (<= 143 rows of 160 bytes), every lane
-// evaluates 4 neighbouring positions per step with v_qsad_pk_u16_u8, the running best is a (sad, y, x) key so that the first
+// evaluates 4 neighbouring positions of 4 consecutive rows per step with v_qsad_pk_u16_u8, the running best is a (sad, y, x) key so that the first
 // minimum in raster order wins exactly as the reference's strict `<` does; the sums are integer atomics (order-free).
 #include <hip/hip_runtime.h>
 #include "svt_hip_internal.h"
@@ -15,7 +15,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPitch   = 176;      // bytes per staged window row: 11 x 16 (odd multiple of 16 -> rows spread over the LDS banks)
 constexpr int kMaxSide = 128;      // largest search side (pd_process.c:497-498)
-constexpr int kRows    = kMaxSide + 15;
+constexpr int kYs      = 4;             // search rows per item
+constexpr int kRows    = kMaxSide + 15 + kYs; // + the rows a partial last group reads past the staged window
 
 struct DgParams {
     DevPlane         src, ref;     // sixteenth planes
@@ -34,6 +35,46 @@ __device__ __forceinline__ void clip_axis(int org, int &origin, int &size, int p
         const int cropped = size - ((org + origin + size) - dim);
         size              = cropped > 1 ? cropped : 1;
     }
+}
+
+// Search of the staged window: item = (group of YS consecutive search rows, quad of columns 4q .. 4q+3).  The YS + 15 window rows of a
+// group are read once and feed all its rows (95 LDS reads per 256 qsads at YS = 4, instead of 320).  Returns this lane's best key
+// (sad << 16) | (y << 8) | x : sad <= 16*16*255 < 2^16, x and y < 128.
+template <int YS> __device__ __forceinline__ uint32_t dg_search(const uint8_t *win, const uint32_t (&s)[16][4], int sa_w, int sa_h, int tid) {
+    const int qpr = (sa_w + 3) >> 2, ngrp = (sa_h + YS - 1) / YS;
+    const float rq = __builtin_amdgcn_rcpf((float)qpr);
+    uint32_t  best = 0xFFFFFFFFu;
+    for (int i = tid; i < ngrp * qpr; i += kThreads) {
+        const int g = (int)(((float)i + 0.5f) * rq), q = i - g * qpr, y0 = g * YS; // exact: i < 2^21
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&win[y0 * kPitch + q * 4]);
+        unsigned long long acc[YS]; // 4 x u16 each: 64 qsads x 4 x 255 = 65280 cannot overflow a lane
+#pragma unroll
+        for (int yy = 0; yy < YS; yy++) acc[yy] = 0;
+#pragma unroll
+        for (int wr = 0; wr < YS + 15; wr++) {
+            uint32_t wv[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) wv[j] = w[wr * (kPitch / 4) + j];
+#pragma unroll
+            for (int yy = 0; yy < YS; yy++) {
+                const int r = wr - yy; // block row that window row wr is for search row y0 + yy
+                if (r >= 0 && r < 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[yy] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)wv[j + 1] << 32) | wv[j], s[r][j], acc[yy]);
+                }
+            }
+        }
+#pragma unroll
+        for (int yy = 0; yy < YS; yy++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = q * 4 + k, y = y0 + yy;
+                const uint32_t key = ((uint32_t)((acc[yy] >> (16 * k)) & 0xFFFF) << 16) | ((uint32_t)y << 8) | (uint32_t)x;
+                if (x < sa_w && y < sa_h && key < best) best = key; // rows / columns past the area read staged-or-stale LDS: masked here
+            }
+    }
+    return best;
 }
 
 __global__ __launch_bounds__(kThreads) void dg_hme_level0_kernel(const DgParams p) {
@@ -66,34 +107,14 @@ __global__ __launch_bounds__(kThreads) void dg_hme_level0_kernel(const DgParams 
     }
     __syncthreads();
 
-    // ---- search: item = (row y, quad of columns 4q .. 4q+3) ----
+    // ---- search ----
     uint32_t s[16][4];
 #pragma unroll
     for (int r = 0; r < 16; r++)
 #pragma unroll
         for (int j = 0; j < 4; j++) s[r][j] = blk[r * 4 + j]; // same address in every lane: broadcast
-    const int qpr  = (sa_w + 3) >> 2;
-    uint32_t  best = 0xFFFFFFFFu; // (sad << 16) | (y << 8) | x : sad <= 16*16*255 < 2^16, x and y < 128
-    for (int i = tid; i < sa_h * qpr; i += kThreads) {
-        const int y = i / qpr, q = i - y * qpr;
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&win[y * kPitch + q * 4]);
-        unsigned long long acc = 0; // 4 x u16: 64 qsads x 4 x 255 = 65280 cannot overflow a lane
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            uint32_t wv[5];
-#pragma unroll
-            for (int j = 0; j < 5; j++) wv[j] = w[r * (kPitch / 4) + j];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)wv[j + 1] << 32) | wv[j], s[r][j], acc);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = q * 4 + k;
-            const uint32_t key = ((uint32_t)((acc >> (16 * k)) & 0xFFFF) << 16) | ((uint32_t)y << 8) | (uint32_t)x;
-            if (x < sa_w && key < best) best = key;
-        }
-    }
+    // small areas (the 16-squared one of low resolutions) have too few row groups to occupy the workgroup: one row per item there
+    uint32_t best = (sa_h * ((sa_w + 3) >> 2) >= kYs * kThreads) ? dg_search<kYs>(win, s, sa_w, sa_h, tid) : dg_search<1>(win, s, sa_w, sa_h, tid);
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t < best ? t : best; }
     if ((tid & 63) == 0) wave_key[tid >> 6] = best;
     __syncthreads();
