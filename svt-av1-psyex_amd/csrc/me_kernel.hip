@@ -625,6 +625,21 @@ __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
     best        = k < best ? k : best;
 }
 
+// all threads: the window whose top-left sample is pix0 displaced by (wx0, wy0), sample by sample, coordinates clamped into the
+// padded plane.  Rare (see run_me_searches): kept out of line so that it costs the common path no registers.
+#ifdef SVT_ME_CLAMP_INLINE
+__device__ __forceinline__
+#else
+__device__ __attribute__((noinline))
+#endif
+void stage_clamped(uint8_t *win, const MeReq &m, int wx0, int wy0, int pitch, int rows) {
+    for (int i = threadIdx.x; i < pitch * rows; i += kThreads) {
+        const int row = i / pitch, cb = i - row * pitch;
+        const int x = imin(imax(wx0 + cb, (int)m.min_x), (int)m.max_x), y = imin(imax(wy0 + row, (int)m.min_y), (int)m.max_y);
+        win[row * pitch + cb] = m.pix0[x + (long long)y * m.stride];
+    }
+}
+
 // all threads: integer search for the refs in st.me[0..nme).  `merge` semantics follow the reference: strict
 // `<` against what is already in best_sad (initial MAX_SAD_VALUE, or the probe's result).
 __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count) {
@@ -676,11 +691,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                         *reinterpret_cast<V4 *>(&sh.win[row * pitch + c * 16]) = v;
                     }
                 } else {
-                    for (int i = threadIdx.x; i < pitch * rows; i += kThreads) {
-                        const int row = i / pitch, cb = i - row * pitch;
-                        const int x = imin(imax(wx0 + cb, (int)m.min_x), (int)m.max_x), y = imin(imax(wy0 + row, (int)m.min_y), (int)m.max_y);
-                        sh.win[row * pitch + cb] = m.pix0[x + (long long)y * m.stride];
-                    }
+                    stage_clamped(sh.win, m, wx0, wy0, pitch, rows);
                 }
                 __syncthreads();
                 const int ng = ((shift & 3) + w + 3) >> 2;
