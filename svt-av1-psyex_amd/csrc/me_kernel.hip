@@ -251,7 +251,7 @@ __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, in
 
 // lane 0: cut the pending requests into tiles whose reference windows fit the LDS arena.  Every request is
 // cut on a fixed (cur_tw x cur_th) grid chosen so that any of its tiles fits an empty arena.
-__device__ void plan_tiles(St &st, bool first) {
+__device__ __attribute__((noinline)) void plan_tiles(St &st, bool first) { // the rare path: out of line
     if (first) { st.next_req = 0; st.next_x = 0; st.next_y = 0; }
     uint32_t used = 0, items = 0, vecs = 0;
     int      nt = 0;
@@ -627,12 +627,7 @@ __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
 
 // all threads: the window whose top-left sample is pix0 displaced by (wx0, wy0), sample by sample, coordinates clamped into the
 // padded plane.  Rare (see run_me_searches): kept out of line so that it costs the common path no registers.
-#ifdef SVT_ME_CLAMP_INLINE
-__device__ __forceinline__
-#else
-__device__ __attribute__((noinline))
-#endif
-void stage_clamped(uint8_t *win, const MeReq &m, int wx0, int wy0, int pitch, int rows) {
+__device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const MeReq &m, int wx0, int wy0, int pitch, int rows) {
     for (int i = threadIdx.x; i < pitch * rows; i += kThreads) {
         const int row = i / pitch, cb = i - row * pitch;
         const int x = imin(imax(wx0 + cb, (int)m.min_x), (int)m.max_x), y = imin(imax(wy0 + row, (int)m.min_y), (int)m.max_y);
