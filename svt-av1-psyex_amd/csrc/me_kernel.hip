@@ -418,16 +418,8 @@ __device__ __forceinline__ void quad_sad_rows(const uint8_t *src, int src_pitch,
     out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
 }
 
-__device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0,
-                                         int r1, uint32_t out[4]) {
-    switch (bw) { // wave-uniform for all practical batches (one block width per HME level)
-    case 16: quad_sad_rows<4>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 32: quad_sad_rows<8>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 64: quad_sad_rows<16>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 8: quad_sad_rows<2>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 4: quad_sad_rows<1>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    default: break;
-    }
+// block widths without a fixed-size path (right-edge blocks of pictures whose width is not a multiple of 64): rare, out of line
+__device__ __attribute__((noinline)) uint4 quad_sad_generic(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0, int r1) {
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if ((bw & 3) == 0) { // other multiples of 4 (right-edge blocks): generic dword loop
         const int nd = bw >> 2;
@@ -455,7 +447,21 @@ __device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, cons
             }
         }
     }
-    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+    return make_uint4(a0, a1, a2, a3);
+}
+
+__device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0,
+                                         int r1, uint32_t out[4]) {
+    switch (bw) { // wave-uniform for all practical batches (one block width per HME level)
+    case 16: quad_sad_rows<4>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 32: quad_sad_rows<8>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 64: quad_sad_rows<16>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 8: quad_sad_rows<2>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 4: quad_sad_rows<1>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    default: break;
+    }
+    const uint4 v = quad_sad_generic(src, src_pitch, wrow0, pitch, rs, bw, r0, r1);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 }
 
 __device__ __forceinline__ void lds_min_u64(u64 *addr, u64 v) { atomicMin(addr, v); }
