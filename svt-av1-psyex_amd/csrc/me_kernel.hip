@@ -227,6 +227,18 @@ __device__ __forceinline__ uint32_t tile_bytes(const Req &r, int shift, int w, i
     return row_pitch(sh, w, r.bw) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1) + 16u; // + slack for the last row's over-read
 }
 
+// items per search row of a tile: quads of positions (LDS columns 4g .. 4g+3 from the dword below the first one) for narrow tiles,
+// octets for wide ones
+#ifndef SVT_ME_WIDE_QUADS
+constexpr int kWideShift = 3;
+#else
+constexpr int kWideShift = 2;
+#endif
+__device__ __forceinline__ uint32_t tile_groups(int shift, int w, int narrow) {
+    const uint32_t quads = (uint32_t)((shift & 3) + w + 3) >> 2;
+    return (narrow || kWideShift == 2) ? quads : (quads + 1) >> 1;
+}
+
 __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, int x0, int y0, int w, int h, int shift, uint32_t lds_off,
                                           uint32_t item0, uint32_t vec0) {
     const int narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
@@ -239,7 +251,7 @@ __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, in
     t.x0 = (int16_t)x0; t.y0 = (int16_t)y0; t.w = (int16_t)w; t.h = (int16_t)h;
     t.pitch     = (uint16_t)row_pitch(shift, w, r.bw);
     t.shift     = (uint16_t)shift;
-    t.ng        = (uint32_t)((shift & 3) + w + 3) >> 2;
+    t.ng        = tile_groups(shift, w, narrow);
     t.slices    = narrow ? (uint32_t)(r.bh + kRowsPerSlice - 1) / kRowsPerSlice : 1u;
     t.item0     = item0;
     t.nitems    = t.ng * (uint32_t)h * t.slices;
@@ -310,7 +322,7 @@ __device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
         shift = (int)((uintptr_t)r.win & 15);
         const uint32_t pitch = row_pitch(shift, r.sa_w, r.bw);
         const uint32_t rows  = (uint32_t)(r.sa_h - 1 + (r.bh - 1) * r.rs + 1);
-        const uint32_t ng    = (uint32_t)((shift & 3) + r.sa_w + 3) >> 2;
+        const uint32_t ng    = tile_groups(shift, r.sa_w, r.sa_w * r.sa_h <= kNarrowMaxPos);
         need  = pitch * rows + 16u;
         items = ng * (uint32_t)r.sa_h * ((r.sa_w * r.sa_h <= kNarrowMaxPos) ? (uint32_t)(r.bh + kRowsPerSlice - 1) / kRowsPerSlice : 1u);
         vecs  = (pitch >> 4) * rows;
@@ -464,6 +476,49 @@ __device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, cons
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 }
 
+// Wide tiles evaluate 8 neighbouring positions per item: the second quad starts one dword further, so a row costs NDW + 2
+// window reads (and NDW source reads) for 2 * NDW qsads instead of 2 * NDW + 2 (and 2 * NDW).
+template <int NDW>
+__device__ __forceinline__ void oct_sad_rows(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int r0, int r1, uint32_t out[8]) {
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int kRowsPerFlush = 64 / NDW;
+    for (int rb = r0; rb < r1; rb += kRowsPerFlush) {
+        const int re = rb + kRowsPerFlush < r1 ? rb + kRowsPerFlush : r1;
+        u64       acc0 = 0, acc1 = 0;
+        for (int r = rb; r < re; r++) {
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * rs * src_pitch);
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
+            uint32_t sv[NDW], wv[NDW + 2];
+#pragma unroll
+            for (int j = 0; j < NDW; j++) sv[j] = s[j];
+#pragma unroll
+            for (int j = 0; j < NDW + 2; j++) wv[j] = w[j];
+#pragma unroll
+            for (int j = 0; j < NDW; j++) {
+                acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 1] << 32) | wv[j], sv[j], acc0);
+                acc1 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 2] << 32) | wv[j + 1], sv[j], acc1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] += (uint32_t)((acc0 >> (16 * i)) & 0xFFFF); a[4 + i] += (uint32_t)((acc1 >> (16 * i)) & 0xFFFF); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = a[i];
+}
+
+__device__ __forceinline__ void oct_sad(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0, int r1, uint32_t out[8]) {
+    switch (bw) {
+    case 16: oct_sad_rows<4>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 32: oct_sad_rows<8>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 64: oct_sad_rows<16>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 8: oct_sad_rows<2>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 4: oct_sad_rows<1>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    default: break;
+    }
+    quad_sad(src, src_pitch, wrow0, pitch, rs, bw, r0, r1, out);         // other widths: two quads
+    quad_sad(src, src_pitch, wrow0 + 4, pitch, rs, bw, r0, r1, out + 4);
+}
+
 __device__ __forceinline__ void lds_min_u64(u64 *addr, u64 v) { atomicMin(addr, v); }
 
 // all threads: evaluate every item of the current plan.  Wide tiles: a thread keeps the running best of the positions
@@ -485,13 +540,13 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
         const int   slice = t.narrow ? (int)div_by_rcp(q, t.h_rcp) : 0, y = (int)q - slice * t.h;
         const int   ysearch = t.y0 + y;
         if (t.skip_even && !(ysearch & 1)) continue;
-        // the quad covers LDS columns col0 .. col0+3 of the tile's rows; tile-relative x = column - shift
-        const int col0 = (t.shift & ~3) + 4 * g;
+        // the quad (octet, for wide tiles) covers LDS columns col0 .. col0+3 (+7) of the tile's rows; tile-relative x = column - shift
+        const int col0 = (t.shift & ~3) + (t.narrow ? 4 : (1 << kWideShift)) * g;
         const int xq   = col0 - t.shift;
         const uint8_t *wrow0 = &sh.win[t.lds_off + y * t.pitch + col0];
         const uint8_t *src   = src_view(sh, t.level);
         const int      sp    = (t.level == 2) ? kSrc64Pitch : (t.level == 1 ? kSrc32Pitch : kSrc16Pitch);
-        uint32_t       s4[4];
+        uint32_t       s4[8];
         if (t.narrow) {
             quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, (int)t.bh), s4);
             for (int i = 0; i < 4; i++) {
@@ -504,8 +559,10 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
                 cur_req  = t.req;
                 cur_best = ~0ull;
             }
-            quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, 0, t.bh, s4);
-            for (int i = 0; i < 4; i++) {
+            if (kWideShift == 3) oct_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, 0, t.bh, s4);
+            else quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, 0, t.bh, s4);
+#pragma unroll
+            for (int i = 0; i < (1 << kWideShift); i++) {
                 const int x = xq + i;
                 if (x >= 0 && x < t.w) {
                     const u64 key = ((u64)s4[i] << 32) | ((u64)(uint32_t)ysearch << 16) | (uint32_t)(t.x0 + x);
