@@ -234,9 +234,14 @@ constexpr int kWideShift = 3;
 #else
 constexpr int kWideShift = 2;
 #endif
+#ifdef SVT_ME_NARROW_OCTETS
+constexpr int kNarrowShift = 3;
+#else
+constexpr int kNarrowShift = 2;
+#endif
 __device__ __forceinline__ uint32_t tile_groups(int shift, int w, int narrow) {
     const uint32_t quads = (uint32_t)((shift & 3) + w + 3) >> 2;
-    return (narrow || kWideShift == 2) ? quads : (quads + 1) >> 1;
+    return ((narrow ? kNarrowShift : kWideShift) == 2) ? quads : (quads + 1) >> 1;
 }
 
 __device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, int x0, int y0, int w, int h, int shift, uint32_t lds_off,
@@ -541,15 +546,17 @@ __device__ __forceinline__ void eval_items(Shared &sh) {
         const int   ysearch = t.y0 + y;
         if (t.skip_even && !(ysearch & 1)) continue;
         // the quad (octet, for wide tiles) covers LDS columns col0 .. col0+3 (+7) of the tile's rows; tile-relative x = column - shift
-        const int col0 = (t.shift & ~3) + (t.narrow ? 4 : (1 << kWideShift)) * g;
+        const int col0 = (t.shift & ~3) + (t.narrow ? (1 << kNarrowShift) : (1 << kWideShift)) * g;
         const int xq   = col0 - t.shift;
         const uint8_t *wrow0 = &sh.win[t.lds_off + y * t.pitch + col0];
         const uint8_t *src   = src_view(sh, t.level);
         const int      sp    = (t.level == 2) ? kSrc64Pitch : (t.level == 1 ? kSrc32Pitch : kSrc16Pitch);
         uint32_t       s4[8];
         if (t.narrow) {
-            quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, (int)t.bh), s4);
-            for (int i = 0; i < 4; i++) {
+            if (kNarrowShift == 3) oct_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, (int)t.bh), s4);
+            else quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, (int)t.bh), s4);
+#pragma unroll
+            for (int i = 0; i < (1 << kNarrowShift); i++) {
                 const int x = xq + i;
                 if (x >= 0 && x < t.w) atomicAdd(&st.sadbuf[ti * kNarrowMaxPos + y * t.w + x], s4[i]);
             }
