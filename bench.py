@@ -230,6 +230,16 @@ def cpu_baseline(wl, seconds_target=12.0):
         v, reps = timed(make_work("oracle", "oracle"), seconds_target)
         out = {"value": round(v, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
                "sample": sample.format(reps=reps, rows=rows_total, h=rows_total * 64, w=W) + "; oracle C restatement"}
+    # The checker's other use ("verify parity on every timed run"): the rows just computed on the CPU, once more as one
+    # band, against what the timed GPU steps left in the result buffer for the same picture.
+    pi = PICS.index((CUR, d))
+    desc = abi.MePictureDesc.from_buffer_copy(bytes(wl.descs[(CUR, d)]))
+    desc.b64_row_start, desc.b64_row_count = row_start, rows_total
+    cpu = pyoracle.me_picture("ref" if have_ref else "oracle", cfg, desc, wl.host8[CUR], refs8, search_level=False)
+    gpu = wl.layout.unpack(wl.me_bufs[0].cpu().numpy(), pi)
+    lo, hi = row_start * wl.w64, (row_start + rows_total) * wl.w64
+    bad = [k for k in gpu if not np.array_equal(np.asarray(cpu[k]).reshape(gpu[k].shape)[lo:hi], gpu[k][lo:hi])]
+    out["parity"] = f"ME results of the sample's {rows_total} b64 rows: GPU == {'reference build' if have_ref else 'oracle'}" if not bad else f"MISMATCH in {bad}"
     return out
 
 
