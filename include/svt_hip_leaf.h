@@ -101,6 +101,19 @@ SVT_HIP_DECL_FWD(8, 16) SVT_HIP_DECL_FWD(16, 8) SVT_HIP_DECL_FWD(16, 32) SVT_HIP
 SVT_HIP_DECL_FWD(4, 16) SVT_HIP_DECL_FWD(16, 4) SVT_HIP_DECL_FWD(8, 32) SVT_HIP_DECL_FWD(32, 8) SVT_HIP_DECL_FWD(16, 64) SVT_HIP_DECL_FWD(64, 16)
 #undef SVT_HIP_DECL_FWD
 
+/* svt_handle_transform* (aom_dsp_rtcd.c:440-449; Codec/transforms.c:2374-2543): energy of the discarded frequencies of a 64-point size,
+ * and the kept 32-wide rows packed to the front of the array in place */
+uint64_t svt_handle_transform16x64_hip(int32_t *output);
+uint64_t svt_handle_transform32x64_hip(int32_t *output);
+uint64_t svt_handle_transform64x16_hip(int32_t *output);
+uint64_t svt_handle_transform64x32_hip(int32_t *output);
+uint64_t svt_handle_transform64x64_hip(int32_t *output);
+uint64_t svt_handle_transform16x64_N2_N4_hip(int32_t *output);
+uint64_t svt_handle_transform32x64_N2_N4_hip(int32_t *output);
+uint64_t svt_handle_transform64x16_N2_N4_hip(int32_t *output);
+uint64_t svt_handle_transform64x32_N2_N4_hip(int32_t *output);
+uint64_t svt_handle_transform64x64_N2_N4_hip(int32_t *output);
+
 /* svt_av1_inv_txfm2d_add_{W}x{H} (common_dsp_rtcd.h:100-141; Codec/inv_transforms.c:2459-2716): uint16 planes, bd 8 or 10, the three prototype
  * forms of the reference (squares; rectangles with tx_size + eob; the 4-wide / 4-high ones with tx_size).  TxType / TxSize are one-byte enums. */
 #define SVT_HIP_DECL_INV_SQ(W, H) void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, int32_t bd);

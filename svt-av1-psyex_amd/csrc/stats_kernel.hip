@@ -1231,3 +1231,57 @@ SVT_HIP_FWD(8, 16, 7) SVT_HIP_FWD(16, 8, 8) SVT_HIP_FWD(16, 32, 9) SVT_HIP_FWD(3
 SVT_HIP_FWD(16, 4, 14) SVT_HIP_FWD(8, 32, 15) SVT_HIP_FWD(32, 8, 16) SVT_HIP_FWD(16, 64, 17) SVT_HIP_FWD(64, 16, 18)
 #undef SVT_HIP_FWD
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// svt_handle_transform{16x64,32x64,64x16,64x32,64x64}{,_N2_N4} (aom_dsp_rtcd.c:440-449; Codec/transforms.c:2374-2543): energy of
+// the frequencies a 64-point size discards + in-place packing of the kept 32-wide rows, on a host coefficient array.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) handle_transform_kernel(const int32_t *in, int w, int h, int with_energy, int32_t *packed, u64 *energy) {
+    __shared__ u64 part[4];
+    const int wp = w > 32 ? 32 : w, hp = h > 32 ? 32 : h;
+    u64 e = 0;
+    for (int i = threadIdx.x; i < w * h; i += 256) {
+        const int r = i / w, c = i - r * w;
+        const int32_t v = in[i];
+        if (r < hp && c < wp) packed[r * wp + c] = v;
+        else if (with_energy) e += (u64)((i64)v * v);
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor((unsigned long long)e, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) *energy = part[0] + part[1] + part[2] + part[3];
+}
+
+uint64_t leaf_handle_transform(int32_t *output, int w, int h, int with_energy) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    const int    wp = w > 32 ? 32 : w, hp = h > 32 ? 32 : h;
+    const size_t ib = align256((size_t)w * h * 4), pb = align256((size_t)wp * hp * 4);
+    uint8_t *base = leaf_scratch(ctx, ib + pb + 256);
+    leaf_check(ctx, hipMemcpyAsync(base, output, (size_t)w * h * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    hipLaunchKernelGGL(handle_transform_kernel, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const int32_t *>(base), w, h, with_energy,
+                       reinterpret_cast<int32_t *>(base + ib), reinterpret_cast<u64 *>(base + ib + pb));
+    leaf_check(ctx, hipGetLastError(), "handle_transform_kernel launch");
+    uint64_t e = 0;
+    // only the 64-wide sizes are re-packed (rows of 64 -> rows of 32 at the front of the array; what lies behind keeps its content)
+    if (w == 64) leaf_check(ctx, hipMemcpyAsync(output, base + ib, (size_t)wp * hp * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(&e, base + ib + pb, 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return e;
+}
+} // namespace
+
+extern "C" {
+uint64_t svt_handle_transform16x64_hip(int32_t *output) { return leaf_handle_transform(output, 16, 64, 1); }
+uint64_t svt_handle_transform32x64_hip(int32_t *output) { return leaf_handle_transform(output, 32, 64, 1); }
+uint64_t svt_handle_transform64x16_hip(int32_t *output) { return leaf_handle_transform(output, 64, 16, 1); }
+uint64_t svt_handle_transform64x32_hip(int32_t *output) { return leaf_handle_transform(output, 64, 32, 1); }
+uint64_t svt_handle_transform64x64_hip(int32_t *output) { return leaf_handle_transform(output, 64, 64, 1); }
+uint64_t svt_handle_transform16x64_N2_N4_hip(int32_t *output) { (void)output; return 0; } // the reference's bodies are empty too (transforms.c:2514-2521)
+uint64_t svt_handle_transform32x64_N2_N4_hip(int32_t *output) { (void)output; return 0; }
+uint64_t svt_handle_transform64x16_N2_N4_hip(int32_t *output) { return leaf_handle_transform(output, 64, 16, 0); }
+uint64_t svt_handle_transform64x32_N2_N4_hip(int32_t *output) { return leaf_handle_transform(output, 64, 32, 0); }
+uint64_t svt_handle_transform64x64_N2_N4_hip(int32_t *output) { return leaf_handle_transform(output, 64, 64, 0); }
+} // extern "C"

@@ -256,3 +256,23 @@ def test_rd_chain_oracle_equals_reference_chain(ref, oracle, ts, impl):
             b = pyoracle.rd_batch(f, src, pred, jobs, rows, impl=impl)
             for k in a:
                 assert np.array_equal(a[k], b[k]), (ts, bd, pattern, k, np.argwhere(a[k] != b[k])[:3].tolist())
+
+
+def test_handle_transform_semantics_against_reference(ref):
+    """svt_handle_transform*_c (transforms.c:2374-2543): what tests/test_rd_gpu.py::test_leaf_handle_transform expects of the `_hip`
+    entries -- energy of everything outside the kept min(W,32) x min(H,32), kept rows packed to the front for the 64-wide sizes, the rest
+    of the array untouched; the _N2_N4 forms only pack."""
+    rng = np.random.default_rng(55)
+    for (w, h) in [(16, 64), (32, 64), (64, 16), (64, 32), (64, 64)]:
+        for suf in ("", "_N2_N4"):
+            fn = getattr(ref, f"svt_handle_transform{w}x{h}{suf}_c")
+            fn.restype = C.c_uint64
+            a = rng.integers(-(1 << 22), 1 << 22, w * h).astype(np.int32)
+            m = a.reshape(h, w).astype(np.int64)
+            wp, hp = min(w, 32), min(h, 32)
+            want = a.copy()
+            if w == 64:
+                want[:wp * hp] = m[:hp, :wp].reshape(-1)
+            energy = int((m ** 2).sum() - (m[:hp, :wp] ** 2).sum()) if suf == "" else 0
+            got = a.copy()
+            assert fn(p(got)) == energy and np.array_equal(got, want), (w, h, suf)

@@ -217,3 +217,30 @@ def test_leaf_forward_transforms(hip_ctx, oracle, tx_size):
                     assert np.array_equal(got, want.reshape(-1)), (tt, bd, pat, suf)
     finally:
         L.svt_hip_leaf_bind(None)
+
+
+def test_leaf_handle_transform(hip_ctx):
+    """svt_handle_transform{16x64,32x64,64x16,64x32,64x64}{,_N2_N4}_hip (transforms.c:2374-2543): the energy of the discarded
+    frequencies, the kept rows packed in place, the rest of the array untouched."""
+    import ctypes as C
+    from svt_av1_psyex_amd import api
+    L = api.lib()
+    assert L.svt_hip_leaf_bind(hip_ctx._h) == 0
+    try:
+        rng = np.random.default_rng(55)
+        for (w, h) in [(16, 64), (32, 64), (64, 16), (64, 32), (64, 64)]:
+            for suf in ("", "_N2_N4"):
+                fn = getattr(L, f"svt_handle_transform{w}x{h}{suf}_hip")
+                fn.restype = C.c_uint64
+                a = rng.integers(-(1 << 22), 1 << 22, w * h).astype(np.int32)
+                want = a.copy()
+                m = a.reshape(h, w).astype(np.int64)
+                wp, hp = min(w, 32), min(h, 32)
+                energy = int((m ** 2).sum() - (m[:hp, :wp] ** 2).sum()) if suf == "" else 0
+                if w == 64:
+                    want[:wp * hp] = m[:hp, :wp].reshape(-1)
+                got = a.copy()
+                e = fn(got.ctypes.data_as(C.c_void_p))
+                assert e == energy and np.array_equal(got, want), (w, h, suf)
+    finally:
+        L.svt_hip_leaf_bind(None)
