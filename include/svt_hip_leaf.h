@@ -129,6 +129,7 @@ SVT_HIP_DECL_INV_SMALL(4, 8) SVT_HIP_DECL_INV_SMALL(8, 4) SVT_HIP_DECL_INV_SMALL
 
 /* svt_aom_sse (aom_dsp_rtcd.h:53), svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (common_dsp_rtcd.h:164-168) */
 int64_t  svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height);
+int64_t  svt_aom_highbd_sse_hip(const uint8_t *a8, int a_stride, const uint8_t *b8, int b_stride, int width, int height); /* a8 / b8: uint16_t samples (enc_inter_prediction.c:562) */
 uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
                                                 uint32_t recon_stride, uint32_t area_width, uint32_t area_height);
 uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,

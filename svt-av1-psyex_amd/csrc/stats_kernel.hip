@@ -593,6 +593,12 @@ int64_t svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_
     return (int64_t)leaf_stats(a, (size_t)a_stride, b, (size_t)b_stride, width, height, 8, false).sse;
 }
 
+// svt_aom_highbd_sse (aom_dsp_rtcd.h:56; enc_inter_prediction.c:559-570): the uint8_t pointers ARE the uint16_t pointers (plain cast there)
+int64_t svt_aom_highbd_sse_hip(const uint8_t *a8, int a_stride, const uint8_t *b8, int b_stride, int width, int height) {
+    return (int64_t)leaf_stats(reinterpret_cast<const uint16_t *>(a8), (size_t)a_stride, reinterpret_cast<const uint16_t *>(b8), (size_t)b_stride, width, height, 10,
+                               false).sse;
+}
+
 uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
                                                 uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
     return leaf_stats(input + input_offset, input_stride, recon + recon_offset, recon_stride, (int)area_width, (int)area_height, 8, false).sse;

@@ -140,6 +140,9 @@ def test_leaf_sad_variance_sse(leaf, oracle):
             oracle.orc_spatial_sse16(p(a16), C.c_uint32(1), C.c_uint32(w + 3), p(b16), C.c_int32(2), C.c_uint32(w + 8), C.c_uint32(w - 2), C.c_uint32(h))
         assert leaf.svt_aom_sad_16b_kernel_hip(p(a16), C.c_uint32(w + 3), p(b16), C.c_uint32(w + 8), C.c_uint32(h), C.c_uint32(w)) == \
             oracle.orc_sad_16b(p(a16), C.c_uint32(w + 3), p(b16), C.c_uint32(w + 8), C.c_uint32(h), C.c_uint32(w))
+        leaf.svt_aom_highbd_sse_hip.restype = C.c_int64  # svt_aom_highbd_sse_c (enc_inter_prediction.c:559): the sum the 16-bit distortion kernel forms
+        assert leaf.svt_aom_highbd_sse_hip(p(a16), w + 3, p(b16), w + 8, w, h) == \
+            oracle.orc_spatial_sse16(p(a16), C.c_uint32(0), C.c_uint32(w + 3), p(b16), C.c_int32(0), C.c_uint32(w + 8), C.c_uint32(w), C.c_uint32(h))
 
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32])
