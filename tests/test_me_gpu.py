@@ -202,3 +202,10 @@ def test_search_centre_outside_the_padded_plane(hip_ctx):
     assert tuple(sc[22, 1, 0]) == (16, 184)  # b64 (2, 2): rows 128..143 of a 144-row picture, centre 184 rows further down
     for _ in range(3):
         assert not compare(want, case.run_hip(hip_ctx))
+
+
+@pytest.mark.parametrize("w,h,enc_mode", [(64, 64, 6), (72, 80, 2), (128, 64, 11), (64, 200, 6)])
+def test_smallest_pictures(hip_ctx, w, h, enc_mode):
+    """One b64 (or one row / column of them), partial blocks: windows of every HME level hang over all four picture edges."""
+    case = MeCase(w, h, enc_mode=enc_mode, refs={(0, 0): 0, (1, 0): 3, (0, 1): 1}, seed=w + h + enc_mode)
+    assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))

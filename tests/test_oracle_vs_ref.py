@@ -113,3 +113,10 @@ def test_full_sad_search_method(ref):
         cfg.me_search_method = 1
     case = MeCase(352, 288, enc_mode=6, cfg_edit=full)
     assert not compare(case.run_cpu("ref"), case.run_cpu("oracle"))
+
+
+@pytest.mark.parametrize("w,h,enc_mode", [(64, 64, 6), (72, 80, 2), (128, 64, 11), (64, 200, 6)])
+def test_smallest_pictures_oracle_vs_reference(ref, w, h, enc_mode):
+    """The cases of tests/test_me_gpu.py::test_smallest_pictures: oracle == reference."""
+    case = MeCase(w, h, enc_mode=enc_mode, refs={(0, 0): 0, (1, 0): 3, (0, 1): 1}, seed=w + h + enc_mode)
+    assert not compare(case.run_cpu("ref"), case.run_cpu("oracle"))
