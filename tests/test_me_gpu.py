@@ -209,3 +209,10 @@ def test_smallest_pictures(hip_ctx, w, h, enc_mode):
     """One b64 (or one row / column of them), partial blocks: windows of every HME level hang over all four picture edges."""
     case = MeCase(w, h, enc_mode=enc_mode, refs={(0, 0): 0, (1, 0): 3, (0, 1): 1}, seed=w + h + enc_mode)
     assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
+
+
+def test_8k_picture_matches_oracle(hip_ctx):
+    """The largest resolution class (input_resolution 6): 120 x 68 = 8,100 b64, the widest search areas of the preset tables."""
+    case = MeCase(7680, 4320, enc_mode=6, refs={(0, 0): 0, (1, 0): 2}, cur=1, n_frames=3, seed=3, temporal_layer_index=2)
+    assert case.desc.input_resolution == 6
+    assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
