@@ -684,11 +684,22 @@ __device__ __forceinline__ uint32_t sum16_of_quads(uint32_t v) {
     return t + (uint32_t)__builtin_amdgcn_mov_dpp((int)t, 0x140 /* row_mirror */, 0xF, 0xF, true);
 }
 
+#ifdef SVT_ME_V64_BPERMUTE
+constexpr int kLane64 = 0; // the lane that keeps the 64x64 running best
 __device__ __forceinline__ uint32_t sum64_of_rows(uint32_t v) {
     // v uniform inside each 16-lane row; returns the sum of the 4 rows in all lanes
     uint32_t t = v + (uint32_t)__shfl_xor((int)v, 16, 64);
     return t + (uint32_t)__shfl_xor((int)t, 32, 64);
 }
+#else
+constexpr int kLane64 = 63;
+__device__ __forceinline__ uint32_t sum64_of_rows(uint32_t v) {
+    // v uniform inside each 16-lane row; the sum of the 4 rows, valid in the LAST row (lanes 48..63) only: two DPP row broadcasts
+    // (lane 15 of a row into the next row, then lane 31 into rows 2 and 3) instead of two cross-lane permutes through the LDS unit
+    const uint32_t t = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    return t + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+}
+#endif
 
 __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
     const u64 k = ((u64)sad << 32) | ord;
@@ -793,7 +804,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
         st.wave_best[wave][21 + lane] = b8;
         if ((lane & 3) == 0) st.wave_best[wave][5 + (lane >> 2)] = b16;
         if ((lane & 15) == 0) st.wave_best[wave][1 + (lane >> 4)] = b32;
-        if (lane == 0) st.wave_best[wave][0] = b64;
+        if (lane == kLane64) st.wave_best[wave][0] = b64;
         __syncthreads();
         for (int n = threadIdx.x; n < 85; n += kThreads) {
             u64 k = st.wave_best[0][n];
