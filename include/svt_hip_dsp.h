@@ -13,6 +13,10 @@
  *  -> svt_av1_inv_txfm2d_add_{WxH}                          (Codec/inv_transforms.c:2459-2716)
  *  -> svt_spatial_full_distortion_kernel / svt_full_distortion_kernel16_bits (picture_operators_c.c:65-83, pic_operators.c:174-197)
  * Decision logic (which tx_type wins, rate estimation, RDOQ) stays on the host.
+ *
+ * Also here: the forward and the inverse transform as batches of their own (svt_hip_fwd_txfm_batch, svt_hip_inv_txfm_batch), the
+ * batched block statistics incl. the PSYEX psy-RD term and distortion facades (svt_hip_block_stats_batch, svt_hip_spy_rd_bias),
+ * full-pel prediction from ME results (svt_hip_fullpel_pred{,_batch}) and the scan-order / size helpers.
  */
 #ifndef SVT_HIP_DSP_H
 #define SVT_HIP_DSP_H
