@@ -908,6 +908,13 @@ __device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy) 
 // =================================================================================================
 // The kernel
 // =================================================================================================
+// the wave that runs a block's serial control code asks for issue priority over the evaluation waves of the other resident workgroups
+// (measured: -1 % ME time at priority 2 or 3; the output phases did not gain)
+#ifndef SVT_ME_CTRL_PRIO
+#define SVT_ME_CTRL_PRIO 2
+#endif
+#define CTRL_PRIO(x) __builtin_amdgcn_s_setprio(x)
+
 extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS, (SVT_HIP_ME_WG_PER_CU * (SVT_HIP_ME_THREADS / 64) + 3) / 4)
 svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -1412,6 +1419,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         PROF(2);
         while (step != kEnd) {
             bool run = true;
+            if (tid < 64) CTRL_PRIO(SVT_ME_CTRL_PRIO);
             switch (step) {
             case kZz: run = c.me_early_exit_th || c.me_safe_limit_zz_th; if (run) zz_pre(); break;
             case kPrehme: run = c.prehme_enable; if (run) prehme_pre(bi); break;
@@ -1426,6 +1434,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 // wave 0 has just pushed the stage's searches: it plans their first round right away (same wave: its LDS writes
                 // are in order), so that one barrier publishes requests and plan together
                 if (step < kProbe && tid < 64 && st.nreq) plan_round(st, true);
+                if (tid < 64) CTRL_PRIO(0);
                 __syncthreads();
                 PROF(step == kMain ? 20 : 6 + step);
                 if (step == kC00 && bi == 0 && st.tf_exit) { step = kEnd; continue; } // uniform: LDS value read after the barrier
@@ -1439,6 +1448,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 }
                 PROF(4);
             }
+            if (tid < 64) CTRL_PRIO(SVT_ME_CTRL_PRIO);
             switch (step) { // fold the results in, pick the next stage
             case kZz: if (run) zz_post(); step = kPrehme; break;
             case kPrehme:
@@ -1460,6 +1470,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 if (bi + 1 < n_group) { bi++; step = kC00; } else step = kEnd;
                 break;
             }
+            if (tid < 64) CTRL_PRIO(0);
             if (run && step != kProbe && step != kMain) __syncthreads(); // the probe / final-window plans read what lane 0 itself wrote
             PROF(5);
         }
