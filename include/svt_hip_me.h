@@ -155,7 +155,21 @@ static inline uint32_t svt_hip_me_n_pu(uint8_t enable_me_16x16, uint8_t enable_m
 
 /* ---- context ---- */
 /* device < 0 selects hipGetDevice's current device.  Fails (non-zero) when no gfx950 GPU is usable:
- * the host then keeps its CPU dispatch (fail closed). */
+ * the host then keeps its CPU dispatch (fail closed).
+ *
+ * THREADING CONTRACT.  One context per GPU is shared by all host threads, like the reference's kernel table is shared by its
+ * ME and mode-decision threads (Globals/enc_handle.c:2265,2293; several pictures in flight, Codec/me_process.c:140-172):
+ *   - every SYNCHRONOUS entry (host pointers in, results complete on return: svt_hip_me_picture,
+ *     svt_hip_dg_detector_hme_level0, svt_hip_pa_picture_download, the pointer-level *_hip entries of svt_hip_leaf.h) may be
+ *     called from any number of threads at once; each call runs on a stream, parameter block and result buffer of its own
+ *     (at most 8 such calls execute concurrently, further callers wait);
+ *   - every ASYNCHRONOUS entry (device pointers: *_async, svt_hip_rd_batch, svt_hip_*_txfm_batch, svt_hip_block_stats_batch,
+ *     svt_hip_fullpel_pred*, svt_hip_pa_picture_create*) enqueues on the ONE stream svt_hip_context_stream() returns.  They
+ *     may be called from several threads too (enqueueing is serialised internally), but stream order is call order, and the
+ *     caller owns the device buffers until svt_hip_context_sync() or an event of its own says the work is done;
+ *   - a picture may be used by any entry as soon as svt_hip_pa_picture_create* has returned (other streams wait for its
+ *     planes through an event); destroy it only after the calls that use it have completed;
+ *   - svt_hip_last_error() returns the last message of the CALLING thread. */
 int  svt_hip_context_create(SvtHipContext **ctx, int device);
 void svt_hip_context_destroy(SvtHipContext *ctx);
 const char *svt_hip_last_error(const SvtHipContext *ctx);
@@ -191,7 +205,9 @@ int svt_hip_me_picture(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtH
                        const SvtHipPaPicture *cur, const SvtHipPaPicture *const refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS],
                        SvtHipMeResults *res);
 /* Asynchronous form: `res` holds DEVICE pointers, work is enqueued on the context stream and the call
- * returns immediately (used by bench.py and by the multi-GPU path, which all-gathers device buffers). */
+ * returns without waiting for the GPU (used by bench.py and by the multi-GPU path, which all-gathers device buffers): the
+ * descriptors are copied into a ring of pinned parameter blocks, so up to 4 launches may be enqueued ahead before the call
+ * waits for the oldest one's parameter copy. */
 int svt_hip_me_picture_async(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc,
                              const SvtHipPaPicture *cur,
                              const SvtHipPaPicture *const refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS],

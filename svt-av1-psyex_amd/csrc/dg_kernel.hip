@@ -139,9 +139,9 @@ __global__ __launch_bounds__(kThreads) void dg_hme_level0_kernel(const DgParams 
 
 } // namespace
 
-extern "C" int svt_hip_dg_detector_hme_level0_async(SvtHipContext *ctx, const SvtHipPaPicture *src, const SvtHipPaPicture *ref,
-                                                    uint16_t aligned_width, uint16_t aligned_height, uint8_t input_resolution,
-                                                    SvtHipDgMetrics *metrics_dev, uint32_t *b64_sad_dev, int16_t *b64_mv_dev) {
+// the launch on an explicit stream (the asynchronous entry: the context stream; the synchronous one: its borrowed lane)
+static int dg_launch(SvtHipContext *ctx, hipStream_t stream, const SvtHipPaPicture *src, const SvtHipPaPicture *ref, uint16_t aligned_width,
+                     uint16_t aligned_height, uint8_t input_resolution, SvtHipDgMetrics *metrics_dev, uint32_t *b64_sad_dev, int16_t *b64_mv_dev) {
     if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
     if (!src || !ref || !metrics_dev) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "dg detector: null picture or metrics pointer");
     if (aligned_width == 0 || aligned_height == 0) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "dg detector: empty picture");
@@ -162,10 +162,19 @@ extern "C" int svt_hip_dg_detector_hme_level0_async(SvtHipContext *ctx, const Sv
     p.b64_sad = b64_sad_dev;
     p.b64_mv  = b64_mv_dev;
     SVT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    SVT_HIP_CHECK(ctx, hipMemsetAsync(metrics_dev, 0, sizeof(SvtHipDgMetrics), ctx->stream));
-    hipLaunchKernelGGL(dg_hme_level0_kernel, dim3(p.w64 * p.h64), dim3(kThreads), 0, ctx->stream, p);
+    if (int rc = svt_hip_wait_picture(ctx, stream, src)) return rc;
+    if (int rc = svt_hip_wait_picture(ctx, stream, ref)) return rc;
+    SVT_HIP_CHECK(ctx, hipMemsetAsync(metrics_dev, 0, sizeof(SvtHipDgMetrics), stream));
+    hipLaunchKernelGGL(dg_hme_level0_kernel, dim3(p.w64 * p.h64), dim3(kThreads), 0, stream, p);
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_dg_detector_hme_level0_async(SvtHipContext *ctx, const SvtHipPaPicture *src, const SvtHipPaPicture *ref,
+                                                    uint16_t aligned_width, uint16_t aligned_height, uint8_t input_resolution,
+                                                    SvtHipDgMetrics *metrics_dev, uint32_t *b64_sad_dev, int16_t *b64_mv_dev) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    return dg_launch(ctx, ctx->stream, src, ref, aligned_width, aligned_height, input_resolution, metrics_dev, b64_sad_dev, b64_mv_dev);
 }
 
 extern "C" int svt_hip_dg_detector_hme_level0(SvtHipContext *ctx, const SvtHipPaPicture *src, const SvtHipPaPicture *ref, uint16_t aligned_width,
@@ -174,17 +183,19 @@ extern "C" int svt_hip_dg_detector_hme_level0(SvtHipContext *ctx, const SvtHipPa
     if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
     if (!metrics) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "dg detector: null metrics pointer");
     const size_t n = (size_t)((aligned_width + 63) / 64) * ((aligned_height + 63) / 64);
+    SvtHipLaneGuard guard(ctx); // own stream and result buffer: callable from several host threads at once
+    SvtHipLane     *lane = guard.lane();
+    if (!lane) return SVT_HIP_ERR_NO_MEMORY;
     void *scratch = nullptr;
     const size_t off_sad = 64, off_mv = off_sad + n * sizeof(uint32_t);
-    if (int rc = svt_hip_scratch(ctx, off_mv + n * 2 * sizeof(int16_t), &scratch)) return rc;
+    if (int rc = svt_hip_scratch(ctx, lane, off_mv + n * 2 * sizeof(int16_t), &scratch)) return rc;
     uint8_t *d = static_cast<uint8_t *>(scratch);
-    if (int rc = svt_hip_dg_detector_hme_level0_async(ctx, src, ref, aligned_width, aligned_height, input_resolution,
-                                                      reinterpret_cast<SvtHipDgMetrics *>(d), reinterpret_cast<uint32_t *>(d + off_sad),
-                                                      reinterpret_cast<int16_t *>(d + off_mv)))
+    if (int rc = dg_launch(ctx, lane->stream, src, ref, aligned_width, aligned_height, input_resolution, reinterpret_cast<SvtHipDgMetrics *>(d),
+                           reinterpret_cast<uint32_t *>(d + off_sad), reinterpret_cast<int16_t *>(d + off_mv)))
         return rc;
-    SVT_HIP_CHECK(ctx, hipMemcpyAsync(metrics, d, sizeof(SvtHipDgMetrics), hipMemcpyDeviceToHost, ctx->stream));
-    if (b64_sad) SVT_HIP_CHECK(ctx, hipMemcpyAsync(b64_sad, d + off_sad, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (b64_mv) SVT_HIP_CHECK(ctx, hipMemcpyAsync(b64_mv, d + off_mv, n * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
-    SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SVT_HIP_CHECK(ctx, hipMemcpyAsync(metrics, d, sizeof(SvtHipDgMetrics), hipMemcpyDeviceToHost, lane->stream));
+    if (b64_sad) SVT_HIP_CHECK(ctx, hipMemcpyAsync(b64_sad, d + off_sad, n * sizeof(uint32_t), hipMemcpyDeviceToHost, lane->stream));
+    if (b64_mv) SVT_HIP_CHECK(ctx, hipMemcpyAsync(b64_mv, d + off_mv, n * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, lane->stream));
+    SVT_HIP_CHECK(ctx, hipStreamSynchronize(lane->stream));
     return SVT_HIP_OK;
 }

@@ -1700,9 +1700,11 @@ size_t svt_hip_me_kernel_lds_bytes(void) { return sizeof(Shared); }
 
 #include "svt_hip_internal.h"
 
-// Host launcher: zero the band queues, copy the header + parameter blocks to HBM (stream ordered: the previous launch
-// has consumed the buffer before this copy lands) and enqueue the persistent workgroups on the context stream.
-int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures) {
+// Host launcher: zero the lane's band queues, copy the header + parameter blocks to HBM through one block of the lane's
+// pinned ring (stream ordered: the previous launch on this lane has consumed the device block before the copy lands; the ring
+// lets SVT_HIP_PARAM_RING launches be enqueued ahead before the host has to wait) and enqueue the persistent workgroups on the
+// lane's stream.  The caller holds the lane (lane 0: ctx->async_mu).
+int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures) {
     if (n_pictures == 0 || n_pictures > SVT_HIP_ME_MAX_PICTURES) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "%u pictures in one ME launch (1..%d)", n_pictures, SVT_HIP_ME_MAX_PICTURES);
     MeBatchHeader hdr;
     memset(&hdr, 0, sizeof(hdr));
@@ -1712,23 +1714,26 @@ int svt_hip_me_launch(SvtHipContext *ctx, const MeKernelParams *params, const ui
     const uint32_t total = hdr.job_base[n_pictures];
     if (total == 0) return SVT_HIP_OK;
     // eight contiguous ranges of the job space, one queue each: neighbouring blocks share reference windows -> same XCD L2.
-    // Ranges are cut at multiples of 4 jobs so that a queue boundary does not split a row needlessly finely.
     for (int q = 0; q <= SVT_HIP_ME_QUEUES; q++) hdr.queue_begin[q] = (uint32_t)(((uint64_t)total * q) / SVT_HIP_ME_QUEUES);
-    hdr.queue_head = ctx->queue_head;
-    SVT_HIP_CHECK(ctx, hipMemsetAsync(ctx->queue_head, 0, SVT_HIP_ME_QUEUES * sizeof(uint32_t), ctx->stream));
+    hdr.queue_head = lane->queue_head;
+    SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->queue_head, 0, SVT_HIP_ME_QUEUES * sizeof(uint32_t), lane->stream));
     const size_t lds = sizeof(Shared);
-    static bool  attr_set = false;
-    if (!attr_set) {
+    if (!ctx->me_attr_set) { // per context = per device; racing first calls set the same value
         SVT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(svt_hip_me_b64_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        ctx->me_attr_set = true;
     }
     uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)SVT_HIP_ME_WG_PER_CU; // persistent workgroups: what the launch bounds and the LDS footprint keep resident
     if (grid > total) grid = total;
-    uint8_t *dev = static_cast<uint8_t *>(ctx->me_params);
-    SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev, &hdr, sizeof(hdr), hipMemcpyHostToDevice, ctx->stream));
-    SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev + SVT_HIP_ME_HEADER_BYTES, params, sizeof(MeKernelParams) * n_pictures, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, ctx->stream, reinterpret_cast<const MeBatchHeader *>(dev),
+    const int slot = lane->ring_next;
+    lane->ring_next = (slot + 1) % SVT_HIP_PARAM_RING;
+    SVT_HIP_CHECK(ctx, hipEventSynchronize(lane->params_copied[slot])); // the copy that last read this pinned block has run
+    uint8_t *host = lane->params_host[slot], *dev = lane->params_dev;
+    memcpy(host, &hdr, sizeof(hdr));
+    memcpy(host + SVT_HIP_ME_HEADER_BYTES, params, sizeof(MeKernelParams) * n_pictures);
+    SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * n_pictures, hipMemcpyHostToDevice, lane->stream));
+    SVT_HIP_CHECK(ctx, hipEventRecord(lane->params_copied[slot], lane->stream));
+    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
                        reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES));
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;

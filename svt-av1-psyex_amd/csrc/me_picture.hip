@@ -2,6 +2,7 @@
 // parameter block assembly, launch, and the synchronous host-pointer form.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <mutex>
 #include "svt_hip_internal.h"
 
 #include <stddef.h>
@@ -96,10 +97,9 @@ size_t layout(const Geometry &g, const SvtHipMePictureDesc *d, const SvtHipMeRes
 
 } // namespace
 
-extern "C" {
-
-int svt_hip_me_pictures_async(SvtHipContext *ctx, uint32_t n_pictures, const SvtHipMeJob *jobs) {
-    if (!ctx || !jobs || n_pictures == 0) return SVT_HIP_ERR_BAD_PARAM;
+// The launch of `n_pictures` pictures on an explicit lane, whose holder is the caller.
+int svt_hip_me_pictures_on_lane(SvtHipContext *ctx, SvtHipLane *lane, uint32_t n_pictures, const SvtHipMeJob *jobs) {
+    if (!ctx || !lane || !jobs || n_pictures == 0) return SVT_HIP_ERR_BAD_PARAM;
     if (n_pictures > SVT_HIP_ME_MAX_PICTURES) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "%u pictures in one call (at most %d)", n_pictures, SVT_HIP_ME_MAX_PICTURES);
     static thread_local MeKernelParams params[SVT_HIP_ME_MAX_PICTURES];
     uint32_t n_jobs[SVT_HIP_ME_MAX_PICTURES];
@@ -122,7 +122,23 @@ int svt_hip_me_pictures_async(SvtHipContext *ctx, uint32_t n_pictures, const Svt
         n_jobs[i] = g.nrow * g.w64;
     }
     hipSetDevice(ctx->device);
-    return svt_hip_me_launch(ctx, params, n_jobs, n_pictures);
+    // pictures whose planes were filled on another stream (svt_hip_pa_picture_create* enqueue on the context stream)
+    for (uint32_t i = 0; i < n_pictures; i++) {
+        const SvtHipMeJob &j = jobs[i];
+        if (int rc = svt_hip_wait_picture(ctx, lane->stream, j.cur)) return rc;
+        for (int li = 0; li < j.desc->num_of_list_to_search; li++)
+            for (int ri = 0; ri < j.desc->num_of_ref_pic_to_search[li]; ri++)
+                if (int rc = svt_hip_wait_picture(ctx, lane->stream, j.refs[li][ri])) return rc;
+    }
+    return svt_hip_me_launch(ctx, lane, params, n_jobs, n_pictures);
+}
+
+extern "C" {
+
+int svt_hip_me_pictures_async(SvtHipContext *ctx, uint32_t n_pictures, const SvtHipMeJob *jobs) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    std::lock_guard<std::mutex> lk(ctx->async_mu); // lane 0's queue counters and parameter ring
+    return svt_hip_me_pictures_on_lane(ctx, &ctx->lane[0], n_pictures, jobs);
 }
 
 int svt_hip_me_picture_async(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, const SvtHipPaPicture *cur,
@@ -141,13 +157,22 @@ int svt_hip_me_picture(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtH
     int rc = validate(ctx, cfg, desc, cur, refs, res, &g);
     if (rc) return rc;
     hipSetDevice(ctx->device);
+    // a lane of its own for the duration of the call: stream, queue counters, parameter block and result buffer are not shared
+    // with calls made from other host threads (Globals/enc_handle.c:2265: several ME threads, several pictures in flight)
+    SvtHipLaneGuard guard(ctx);
+    SvtHipLane     *lane = guard.lane();
+    if (!lane) return SVT_HIP_ERR_NO_MEMORY;
     Field           f[16];
     SvtHipMeResults dev;
     const size_t    bytes = layout(g, desc, res, &dev, nullptr, f);
     void           *scratch;
-    if ((rc = svt_hip_scratch(ctx, bytes, &scratch))) return rc;
+    if ((rc = svt_hip_scratch(ctx, lane, bytes, &scratch))) return rc;
     layout(g, desc, res, &dev, static_cast<uint8_t *>(scratch), f);
-    if ((rc = svt_hip_me_picture_async(ctx, cfg, desc, cur, refs, &dev))) return rc;
+    SvtHipMeJob job;
+    job.cfg = cfg; job.desc = desc; job.cur = cur; job.results = &dev;
+    for (int li = 0; li < SVT_HIP_MAX_LISTS; li++)
+        for (int ri = 0; ri < SVT_HIP_MAX_REFS; ri++) job.refs[li][ri] = refs[li][ri];
+    if ((rc = svt_hip_me_pictures_on_lane(ctx, lane, 1, &job))) return rc;
     // copy back only the rows of this call's band
     void *const *hp = reinterpret_cast<void *const *>(res);
     void *const *dp = reinterpret_cast<void *const *>(&dev);
@@ -156,9 +181,9 @@ int svt_hip_me_picture(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtH
         const size_t per_b64 = f[i].count / g.n_b64 * f[i].elem;
         const size_t lo = (size_t)g.row0 * g.w64 * per_b64, n = (size_t)g.nrow * g.w64 * per_b64;
         SVT_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t *>(hp[i]) + lo, static_cast<const uint8_t *>(dp[i]) + lo, n, hipMemcpyDeviceToHost,
-                                          ctx->stream));
+                                          lane->stream));
     }
-    SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SVT_HIP_CHECK(ctx, hipStreamSynchronize(lane->stream));
     return SVT_HIP_OK;
 }
 

@@ -3,6 +3,7 @@
 // Codec/pic_operators.c:397-443).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <new>
 #include <string.h>
 #include "svt_hip_internal.h"
 
@@ -90,6 +91,10 @@ int create_common(SvtHipContext *ctx, const SvtHipPlaneDesc *full, const SvtHipP
     if (!rc) rc = upload_plane(ctx, full, &pic->pyr.lvl[2], full_on_device);
     if (!rc) rc = make_level(ctx, pic, 1, quarter);
     if (!rc) rc = make_level(ctx, pic, 0, sixteenth);
+    // whoever reads the planes on another stream (a synchronous entry on a borrowed lane) waits for this event first
+    if (!rc && hipEventCreateWithFlags(&pic->ready, hipEventDisableTiming) != hipSuccess) rc = svt_hip_fail(ctx, SVT_HIP_ERR_LAUNCH, "hipEventCreate failed");
+    if (!rc && hipEventRecord(pic->ready, ctx->stream) != hipSuccess) rc = svt_hip_fail(ctx, SVT_HIP_ERR_LAUNCH, "hipEventRecord failed");
+    pic->ready_stream = ctx->stream;
     if (rc) {
         svt_hip_pa_picture_destroy(ctx, pic);
         return rc;
@@ -113,16 +118,18 @@ int svt_hip_context_create(SvtHipContext **out, int device) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SVT_HIP_ERR_NO_DEVICE;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SVT_HIP_ERR_NO_DEVICE; // code objects are gfx950 only
     if (hipSetDevice(device) != hipSuccess) return SVT_HIP_ERR_NO_DEVICE;
-    SvtHipContext *ctx = static_cast<SvtHipContext *>(calloc(1, sizeof(SvtHipContext)));
+    SvtHipContext *ctx = new (std::nothrow) SvtHipContext();
     if (!ctx) return SVT_HIP_ERR_NO_MEMORY;
     ctx->device  = device;
     ctx->num_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->queue_head), 512) != hipSuccess || hipMemset(ctx->queue_head, 0, 512) != hipSuccess ||
-        hipMalloc(&ctx->me_params, SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * SVT_HIP_ME_MAX_PICTURES) != hipSuccess) {
-        free(ctx);
+    // lane 0 (the asynchronous entries' stream) and this device's transform tables exist from the start; the borrowed
+    // lanes are made when a synchronous entry first needs one
+    if (svt_hip_lane_setup(ctx, &ctx->lane[0], true) != SVT_HIP_OK || svt_hip_rd_tables_init(ctx) != SVT_HIP_OK) {
+        svt_hip_context_destroy(ctx);
         return SVT_HIP_ERR_NO_DEVICE;
     }
+    ctx->stream    = ctx->lane[0].stream;
+    ctx->lane_busy = 1u; // lane 0 is never borrowed
     *out = ctx;
     return SVT_HIP_OK;
 }
@@ -130,15 +137,23 @@ int svt_hip_context_create(SvtHipContext **out, int device) {
 void svt_hip_context_destroy(SvtHipContext *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch) hipFree(ctx->scratch);
-    hipFree(ctx->queue_head);
-    hipFree(ctx->me_params);
-    hipStreamDestroy(ctx->stream);
-    free(ctx);
+    for (int i = 0; i < SVT_HIP_LANES; i++) {
+        SvtHipLane &l = ctx->lane[i];
+        if (l.stream) hipStreamSynchronize(l.stream);
+        if (l.scratch) hipFree(l.scratch);
+        if (l.queue_head) hipFree(l.queue_head);
+        if (l.params_dev) hipFree(l.params_dev);
+        for (int k = 0; k < SVT_HIP_PARAM_RING; k++) {
+            if (l.params_host[k]) hipHostFree(l.params_host[k]);
+            if (l.params_copied[k]) hipEventDestroy(l.params_copied[k]);
+        }
+        if (l.stream) hipStreamDestroy(l.stream);
+    }
+    svt_hip_rd_tables_free(ctx);
+    delete ctx;
 }
 
-const char *svt_hip_last_error(const SvtHipContext *ctx) { return ctx ? ctx->err : "no context"; }
+const char *svt_hip_last_error(const SvtHipContext *) { return svt_hip_err_buf(); }
 void       *svt_hip_context_stream(SvtHipContext *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int svt_hip_context_sync(SvtHipContext *ctx) {
@@ -164,6 +179,7 @@ void svt_hip_pa_picture_destroy(SvtHipContext *ctx, SvtHipPaPicture *pic) {
     }
     for (int l = 0; l < 3; l++)
         if (pic->mem[l]) hipFree(pic->mem[l]);
+    if (pic->ready) hipEventDestroy(pic->ready);
     free(pic);
 }
 
@@ -191,26 +207,80 @@ int svt_hip_pa_picture_download(SvtHipContext *ctx, const SvtHipPaPicture *pic, 
 
 } // extern "C"
 
-int svt_hip_scratch(SvtHipContext *ctx, size_t bytes, void **out) {
-    if (bytes > ctx->scratch_bytes) {
-        if (ctx->scratch) {
-            SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            hipFree(ctx->scratch);
-            ctx->scratch = nullptr;
-            ctx->scratch_bytes = 0;
-        }
-        if (hipMalloc(&ctx->scratch, bytes) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "hipMalloc(%zu) failed", bytes);
-        ctx->scratch_bytes = bytes;
+char *svt_hip_err_buf(void) {
+    static thread_local char buf[SVT_HIP_ERR_BYTES] = "";
+    return buf;
+}
+
+int svt_hip_lane_setup(SvtHipContext *ctx, SvtHipLane *l, bool make_stream) {
+    if (l->ready) return SVT_HIP_OK;
+    if (make_stream) SVT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    if (hipMalloc(reinterpret_cast<void **>(&l->queue_head), 512) != hipSuccess || hipMemset(l->queue_head, 0, 512) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&l->params_dev), SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * SVT_HIP_ME_MAX_PICTURES) != hipSuccess)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMalloc failed");
+    for (int k = 0; k < SVT_HIP_PARAM_RING; k++) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&l->params_host[k]), SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * SVT_HIP_ME_MAX_PICTURES, hipHostMallocDefault) != hipSuccess)
+            return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipHostMalloc failed");
+        SVT_HIP_CHECK(ctx, hipEventCreateWithFlags(&l->params_copied[k], hipEventDisableTiming));
     }
-    *out = ctx->scratch;
+    l->ring_next = 0;
+    l->ready     = true;
     return SVT_HIP_OK;
 }
 
-// Diagnostic: per-phase shader-clock sums of the ME kernel (non-zero only in a -DSVT_HIP_ME_PROFILE build); clears them.
+SvtHipLaneGuard::SvtHipLaneGuard(SvtHipContext *ctx) : ctx_(ctx), lane_(nullptr), index_(-1) {
+    std::unique_lock<std::mutex> lk(ctx->pool_mu);
+    ctx->pool_cv.wait(lk, [&] { return ctx->lane_busy != (1u << SVT_HIP_LANES) - 1u; });
+    for (int i = 1; i < SVT_HIP_LANES; i++)
+        if (!(ctx->lane_busy & (1u << i))) { index_ = i; break; }
+    ctx->lane_busy |= 1u << index_;
+    lk.unlock();
+    hipSetDevice(ctx->device);
+    // only the holder touches a borrowed lane, so its one-time set-up needs no lock
+    if (svt_hip_lane_setup(ctx, &ctx->lane[index_], true) == SVT_HIP_OK) lane_ = &ctx->lane[index_];
+}
+
+SvtHipLaneGuard::~SvtHipLaneGuard() {
+    {
+        std::lock_guard<std::mutex> lk(ctx_->pool_mu);
+        ctx_->lane_busy &= ~(1u << index_);
+    }
+    ctx_->pool_cv.notify_one();
+}
+
+int svt_hip_wait_picture(SvtHipContext *ctx, hipStream_t stream, const SvtHipPaPicture *pic) {
+    if (pic && pic->ready && pic->ready_stream != stream) SVT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, pic->ready, 0));
+    return SVT_HIP_OK;
+}
+
+int svt_hip_scratch(SvtHipContext *ctx, SvtHipLane *l, size_t bytes, void **out) {
+    if (bytes > l->scratch_bytes) {
+        if (l->scratch) {
+            SVT_HIP_CHECK(ctx, hipStreamSynchronize(l->stream));
+            hipFree(l->scratch);
+            l->scratch = nullptr;
+            l->scratch_bytes = 0;
+        }
+        if (hipMalloc(&l->scratch, bytes) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "hipMalloc(%zu) failed", bytes);
+        l->scratch_bytes = bytes;
+    }
+    *out = l->scratch;
+    return SVT_HIP_OK;
+}
+
+// Diagnostic: per-phase shader-clock sums of the ME kernel (non-zero only in a -DSVT_HIP_ME_PROFILE build), summed over the
+// lanes; clears them.
 extern "C" int svt_hip_me_profile_read(SvtHipContext *ctx, unsigned long long out[24]) {
     if (!ctx || !out) return SVT_HIP_ERR_BAD_PARAM;
-    SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    SVT_HIP_CHECK(ctx, hipMemcpy(out, reinterpret_cast<char *>(ctx->queue_head) + 64, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    SVT_HIP_CHECK(ctx, hipMemset(reinterpret_cast<char *>(ctx->queue_head) + 64, 0, 24 * sizeof(unsigned long long)));
+    for (int k = 0; k < 24; k++) out[k] = 0;
+    for (int i = 0; i < SVT_HIP_LANES; i++) {
+        SvtHipLane &l = ctx->lane[i];
+        if (!l.ready) continue;
+        unsigned long long v[24];
+        SVT_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
+        SVT_HIP_CHECK(ctx, hipMemcpy(v, reinterpret_cast<char *>(l.queue_head) + 64, sizeof(v), hipMemcpyDeviceToHost));
+        SVT_HIP_CHECK(ctx, hipMemset(reinterpret_cast<char *>(l.queue_head) + 64, 0, sizeof(v)));
+        for (int k = 0; k < 24; k++) out[k] += v[k];
+    }
     return SVT_HIP_OK;
 }

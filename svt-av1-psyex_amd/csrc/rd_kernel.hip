@@ -758,25 +758,6 @@ int scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) {
     return n;
 }
 
-int16_t *g_iscan_dev = nullptr; // [19][3][1024] inverse scans, device resident
-bool     g_tables_ready = false;
-
-int init_tables(SvtHipContext *ctx) {
-    if (g_tables_ready) return SVT_HIP_OK;
-    static int32_t cosp[4][64];
-    for (int b = 0; b < 4; b++)
-        for (int j = 0; j < 64; j++) cosp[b][j] = (int32_t)(cos(3.14159265358979323846 * j / 128.0) * (double)(1 << (10 + b)) + 0.5);
-    SVT_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_cospi), cosp, sizeof(cosp)));
-    static int16_t tab[19][3][1024], scan[1024];
-    memset(tab, 0, sizeof(tab));
-    for (int s = 0; s < 19; s++)
-        for (int kind = 0; kind < 3; kind++) scan_order(s, kind == 0 ? 0 : (kind == 1 ? 10 : 11), scan, tab[s][kind]);
-    if (hipMalloc(reinterpret_cast<void **>(&g_iscan_dev), sizeof(tab)) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "iscan tables");
-    SVT_HIP_CHECK(ctx, hipMemcpy(g_iscan_dev, tab, sizeof(tab), hipMemcpyHostToDevice));
-    g_tables_ready = true;
-    return SVT_HIP_OK;
-}
-
 } // namespace
 
 extern "C" {
@@ -798,13 +779,11 @@ int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d) {
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the RD batch is null");
     if ((d->qmatrix == nullptr) != (d->iqmatrix == nullptr)) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "qmatrix and iqmatrix go together");
     hipSetDevice(ctx->device);
-    int rc = init_tables(ctx);
-    if (rc) return rc;
     RdParams p;
     p.d       = *d;
     p.tx_size = d->tx_size;
     if (p.tx_size < 0 || p.tx_size >= 19) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %d", p.tx_size);
-    for (int k = 0; k < 3; k++) p.iscan[k] = g_iscan_dev + ((size_t)p.tx_size * 3 + k) * 1024;
+    for (int k = 0; k < 3; k++) p.iscan[k] = ctx->iscan_dev + ((size_t)p.tx_size * 3 + k) * 1024;
     return d->bit_depth == 8 ? launch_size<8>(ctx, p) : launch_size<10>(ctx, p);
 }
 
@@ -928,7 +907,6 @@ extern "C" int svt_hip_inv_txfm_batch(SvtHipContext *ctx, const SvtHipInvTxBatch
     if (d->tx_size >= SVT_HIP_TX_SIZES_ALL) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %u", d->tx_size);
     if (!d->pred || !d->recon || !d->jobs || !d->dqcoeff) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a pointer of the inverse batch is null");
     hipSetDevice(ctx->device);
-    if (int rc = init_tables(ctx)) return rc;
     InvParams p;
     p.d = *d;
     if (d->bit_depth == 10) return launch_inv<10, uint16_t>(ctx, p);
@@ -941,8 +919,31 @@ extern "C" int svt_hip_fwd_txfm_batch(SvtHipContext *ctx, const SvtHipFwdTxBatch
     if (d->tx_size >= SVT_HIP_TX_SIZES_ALL) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "tx_size %u", d->tx_size);
     if (!d->residual || !d->jobs || !d->coeff) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a pointer of the forward batch is null");
     hipSetDevice(ctx->device);
-    if (int rc = init_tables(ctx)) return rc;
     FwdParams p;
     p.d = *d;
     return launch_fwd(ctx, p);
+}
+
+// The cosine table (constant memory of this device's copy of the code object) and the inverse scan orders, made once per
+// context at svt_hip_context_create: no lazily initialised process-global state (several threads, several GPUs per process).
+int svt_hip_rd_tables_init(SvtHipContext *ctx) {
+    int32_t cosp[4][64];
+    for (int b = 0; b < 4; b++)
+        for (int j = 0; j < 64; j++) cosp[b][j] = (int32_t)(cos(3.14159265358979323846 * j / 128.0) * (double)(1 << (10 + b)) + 0.5);
+    SVT_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_cospi), cosp, sizeof(cosp)));
+    const size_t bytes = sizeof(int16_t) * 19 * 3 * 1024;
+    int16_t *tab = static_cast<int16_t *>(calloc(1, bytes)), scan[1024];
+    if (!tab) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "iscan tables");
+    for (int s = 0; s < 19; s++)
+        for (int kind = 0; kind < 3; kind++) scan_order(s, kind == 0 ? 0 : (kind == 1 ? 10 : 11), scan, tab + ((size_t)s * 3 + kind) * 1024);
+    int rc = SVT_HIP_OK;
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->iscan_dev), bytes) != hipSuccess) rc = svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "iscan tables");
+    else if (hipMemcpy(ctx->iscan_dev, tab, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = svt_hip_fail(ctx, SVT_HIP_ERR_LAUNCH, "iscan tables: copy failed");
+    free(tab);
+    return rc;
+}
+
+void svt_hip_rd_tables_free(SvtHipContext *ctx) {
+    if (ctx->iscan_dev) hipFree(ctx->iscan_dev);
+    ctx->iscan_dev = nullptr;
 }

@@ -464,10 +464,11 @@ void leaf_check(SvtHipContext *ctx, hipError_t e, const char *what) {
     }
 }
 
-// device staging area: [0, bytes) carved by the caller
+// device staging area: [0, bytes) carved by the caller.  The pointer-level entries run one at a time (g_leaf_mutex) on the context
+// stream; lane 0's result buffer is theirs alone (the asynchronous entries use none, the synchronous ones borrow other lanes).
 uint8_t *leaf_scratch(SvtHipContext *ctx, size_t bytes) {
     void *pp = nullptr;
-    if (svt_hip_scratch(ctx, bytes, &pp) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: out of device memory in a _hip leaf kernel\n"); abort(); }
+    if (svt_hip_scratch(ctx, &ctx->lane[0], bytes, &pp) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: out of device memory in a _hip leaf kernel\n"); abort(); }
     return static_cast<uint8_t *>(pp);
 }
 
@@ -506,7 +507,7 @@ StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t 
     d.sad = &o->sad; d.variance = &o->variance; d.var_sse = &o->var_sse; d.sse = reinterpret_cast<uint64_t *>(&o->sse); d.satd = want_satd ? &o->satd : nullptr;
     if (bit_depth == 10) { d.variance10 = &o->variance10; d.var_sse10 = &o->var_sse10; }
     if (want_psy) { d.psy_rd = psy_rd; d.psy_energy = reinterpret_cast<uint64_t *>(&o->psy_energy); d.psy_dist = reinterpret_cast<uint64_t *>(&o->psy_dist); }
-    if (svt_hip_block_stats_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    if (svt_hip_block_stats_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
     StatsOut out;
     memset(&out, 0, sizeof(out));
     leaf_check(ctx, hipMemcpyAsync(&out, d_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
@@ -809,7 +810,7 @@ int svt_hip_estimate_transform(int16_t *residual, uint32_t residual_stride, int3
     d.src = d_src; d.pred = d_zero; d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.quant_rows = reinterpret_cast<const SvtHipQuantRow *>(d_row); d.n_quant_rows = 1;
     d.eob = reinterpret_cast<uint16_t *>(d_out); d.satd = reinterpret_cast<uint32_t *>(d_out + 8); d.dist_coeff = reinterpret_cast<uint64_t *>(d_out + 16);
     d.three_quad_energy = reinterpret_cast<uint64_t *>(d_out + 32); d.sse = reinterpret_cast<uint64_t *>(d_out + 40); d.coeff = reinterpret_cast<int32_t *>(d_coeff);
-    if (svt_hip_rd_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    if (svt_hip_rd_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
     leaf_check(ctx, hipMemcpyAsync(coeff, d_coeff, (size_t)NP * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     uint64_t tq = 0;
     leaf_check(ctx, hipMemcpyAsync(&tq, d_out + 32, 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
@@ -1158,7 +1159,7 @@ void leaf_inv_txfm(const int32_t *input, const uint16_t *out_r, int32_t stride_r
     memset(&d, 0, sizeof(d));
     d.bit_depth = (uint8_t)bd; d.sample_bytes = 2; d.tx_size = (uint8_t)tx_size; d.n_jobs = 1; d.pred_stride = (uint32_t)stride_r; d.recon_stride = (uint32_t)W;
     d.pred = d_pred; d.recon = d_rec; d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.dqcoeff = reinterpret_cast<const int32_t *>(d_co);
-    if (svt_hip_inv_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    if (svt_hip_inv_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
     leaf_check(ctx, hipMemcpy2DAsync(out_w, (size_t)stride_w * 2, d_rec, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy2DAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -1215,7 +1216,7 @@ void leaf_fwd_txfm(const int16_t *input, int32_t *output, uint32_t stride, int t
     memset(&d, 0, sizeof(d));
     d.tx_size = (uint8_t)tx_size; d.n_jobs = 1; d.residual_stride = stride; d.residual = reinterpret_cast<const int16_t *>(d_res);
     d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.coeff = reinterpret_cast<int32_t *>(d_out);
-    if (svt_hip_fwd_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", ctx->err); abort(); }
+    if (svt_hip_fwd_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
     leaf_check(ctx, hipMemcpyAsync(output, d_out, obytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
