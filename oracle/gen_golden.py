@@ -254,7 +254,20 @@ def gen_tpl_chain():
     print("tpl_chain.npz", np.stack(res).shape)
 
 
-GENERATORS = {"me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats, "dg": gen_dg_detector, "tpl": gen_tpl_chain}
+def gen_pyramid():
+    """1/4 and 1/16 luma planes with their padding as the reference's picture analysis makes them (ref_harness.c:ref_pyramid ->
+    svt_aom_downsample_filtering_input_picture -> svt_aom_downsample_2d_c + svt_aom_generate_padding) for tests/pyramid_cases.py's
+    pictures.  Stored: the padded quarter / sixteenth planes (tight stride); the inputs are regenerated from the case list."""
+    from pyramid_cases import CASES, luma, ref_pyramid
+    out = {}
+    for name, (w, h, kind, seed) in CASES.items():
+        q, s = ref_pyramid(luma(w, h, kind, seed))
+        out[name + "_q"], out[name + "_s"] = q, s
+        print("pyramid", name, q.shape, s.shape)
+    np.savez_compressed(os.path.join(OUT, "pyramid.npz"), **out)
+
+
+GENERATORS = {"pyramid": gen_pyramid, "me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats, "dg": gen_dg_detector, "tpl": gen_tpl_chain}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

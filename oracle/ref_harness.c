@@ -558,3 +558,30 @@ int ref_tpl_chain(const uint8_t *src, uint32_t src_stride, const uint8_t *pred, 
     out4[3] = sse > 1 ? sse : 1;
     return 0;
 }
+
+/* The luma pyramid exactly as the reference's picture-analysis stage makes it: svt_aom_downsample_filtering_input_picture
+ * (Codec/pic_analysis_process.c:2139-2196) = downsample_2d (`_c`, :130-158) + svt_aom_generate_padding (Codec/pic_operators.c:397-443),
+ * driven with the reference's own PictureParentControlSet flags and EbPictureBufferDesc geometry.  `full` is read, the padded
+ * `quarter` / `sixteenth` buffers (padding 32 / 16, Globals/enc_handle.c:1260-1279) are written.  level1 == 0 takes the
+ * reference's other branch: the sixteenth plane straight from the full plane with decimation step 4. */
+#include "pic_analysis_process.h"
+int ref_pyramid(const SvtHipPlaneDesc *full, const SvtHipPlaneDesc *quarter, const SvtHipPlaneDesc *sixteenth, int level1) {
+    PictureParentControlSet *pcs = (PictureParentControlSet *)calloc(1, sizeof(*pcs));
+    EbPictureBufferDesc      in, q, s;
+    if (!pcs) return 1;
+    memset(&in, 0, sizeof(in)); memset(&q, 0, sizeof(q)); memset(&s, 0, sizeof(s));
+    pcs->enable_hme_flag        = 1;
+    pcs->enable_hme_level0_flag = 1;
+    pcs->enable_hme_level1_flag = level1 ? 1 : 0;
+    downsample_2d = svt_aom_downsample_2d_c;
+    svt_memcpy    = svt_memcpy_c; /* rtcd pointer read by svt_aom_generate_padding */
+    in.buffer_y = (uint8_t *)full->buffer_y; in.stride_y = (uint16_t)full->stride_y; in.org_x = full->org_x; in.org_y = full->org_y;
+    in.width = full->width; in.height = full->height;
+    q.buffer_y = (uint8_t *)quarter->buffer_y; q.stride_y = (uint16_t)quarter->stride_y; q.org_x = quarter->org_x; q.org_y = quarter->org_y;
+    q.width = quarter->width; q.height = quarter->height;
+    s.buffer_y = (uint8_t *)sixteenth->buffer_y; s.stride_y = (uint16_t)sixteenth->stride_y; s.org_x = sixteenth->org_x; s.org_y = sixteenth->org_y;
+    s.width = sixteenth->width; s.height = sixteenth->height;
+    svt_aom_downsample_filtering_input_picture(pcs, &in, &q, &s);
+    free(pcs);
+    return 0;
+}

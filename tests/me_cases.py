@@ -61,6 +61,30 @@ class MeCase:
         import pyoracle
         return pyoracle.me_picture(which, self.cfg, self.desc, self.cur, self.refs)
 
+    def run_cpu_banded(self, which="oracle", threads=8):
+        """run_cpu with the b64 rows of this case's band split over host threads (ctypes releases the GIL): the slow presets at
+        2160p.  Rows outside the case's band stay zero, as in a band call."""
+        import concurrent.futures as cf
+        import pyoracle
+        h64 = (self.height + 63) // 64
+        r0 = self.desc.b64_row_start
+        r1 = r0 + self.desc.b64_row_count if self.desc.b64_row_count else h64
+        w64 = (self.width + 63) // 64
+
+        def band(row):
+            d = abi.MePictureDesc.from_buffer_copy(bytes(self.desc))
+            d.b64_row_start, d.b64_row_count = row, 1
+            return row, pyoracle.me_picture(which, self.cfg, d, self.cur, self.refs)
+
+        out = None
+        with cf.ThreadPoolExecutor(threads) as ex:
+            for row, res in ex.map(band, range(r0, r1)):
+                if out is None:
+                    out = {k: np.zeros_like(v) for k, v in res.items()}
+                for k, v in res.items():
+                    out[k][row * w64:(row + 1) * w64] = v[row * w64:(row + 1) * w64]
+        return out
+
     def run_hip(self, ctx, device_pyramid=True):
         cur = ctx.upload(self.cur, device_pyramid)
         refs = {k: ctx.upload(v, device_pyramid) for k, v in self.refs.items()}
