@@ -72,6 +72,10 @@ typedef struct SvtHipRdBatchDesc {
      * point: pcs->ppcs->gqmatrix / giqmatrix[level][plane][adjusted_tx_size], full_loop.c:1606-1613); applied to the jobs with
      * a 2-D tx_type (tx_type < IDTX), like the reference; NULL = flat */
     const uint8_t *qmatrix, *iqmatrix;
+    /* optional, [n_jobs] (device pointer): svt_av1_compute_cul_level(scan, qcoeff, &eob) (Codec/full_loop.c:1449-1466) -- the value
+     * svt_aom_quantize_inv_quantize returns when rate_est_ctrls.update_skip_ctx_dc_sign_ctx is set (:1832-1836): min(63, sum |qcoeff|)
+     * with the DC sign in bits 6-7 (negative: | 64, positive: + 128); feeds the entropy contexts of the next block's rate estimate */
+    uint8_t *cul_level;
 } SvtHipRdBatchDesc;
 
 /* Enqueues one batch on the context stream (asynchronous).  Every pointer in `d` is a DEVICE pointer.
@@ -184,6 +188,11 @@ typedef struct SvtHipPredJob {
 } SvtHipPredJob;
 int svt_hip_fullpel_pred_batch(SvtHipContext *ctx, uint32_t ref_stride, uint32_t width, uint32_t height, uint8_t bit_depth, uint32_t pred_stride,
                                uint32_t n_jobs, const SvtHipPredJob *jobs);
+
+/* get_hvs_modulation_factor (Codec/psy_rd.c:295-307): the psy-rd strength every psy call site passes on (e.g. product_coding_loop.c:972,
+ * 4618): x0.4 on intra (I-slice) pictures, x0.75 / x0.9 / x0.95 on temporal layers 0 / 1 / 2, unchanged above.  Host arithmetic (one fp64
+ * multiply, same operand order as the reference). */
+double svt_hip_hvs_modulation_factor(double psy_rd, int is_islice, uint8_t temporal_layer_index);
 
 /* Scan order of (tx_size, tx_type) as av1_scan_orders holds it (Codec/coefficients.h:2197); returns the length. */
 int svt_hip_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan);

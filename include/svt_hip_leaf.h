@@ -150,6 +150,9 @@ void svt_aom_hadamard_8x8_hip(const int16_t *src_diff, ptrdiff_t src_stride, int
 void svt_aom_hadamard_16x16_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
 void svt_aom_hadamard_32x32_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff);
 int  svt_aom_satd_hip(const int32_t *coeff, int length);
+/* svt_av1_compute_cul_level (aom_dsp_rtcd.h:904, Codec/full_loop.c:1449-1466), svt_av1_fwht4x4 (aom_dsp_rtcd.h:208, Codec/transforms.c:3099-3151) */
+uint8_t svt_av1_compute_cul_level_hip(const int16_t *const scan, const int32_t *const quant_coeff, uint16_t *eob);
+void    svt_av1_fwht4x4_hip(int16_t *input, int32_t *output, uint32_t stride);
 /* hadamard_path_c (Codec/enc_mode_config.c:2151-2217) with the Buf2D arguments flattened: 8-bit input and prediction,
  * square block of `block_size_wide` (4..128) */
 uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide);

@@ -273,3 +273,51 @@ void orc_quantize_fp(const int32_t *coeff, intptr_t n, const int16_t *round, con
     }
     *eob_out = (uint16_t)(eob + 1);
 }
+
+/* svt_av1_compute_cul_level_c + set_dc_sign: Codec/full_loop.c:1338-1343,1449-1466 (COEFF_CONTEXT_BITS = 6, cabac_context_model.h:435) */
+uint8_t orc_compute_cul_level(const int16_t *scan, const int32_t *quant_coeff, const uint16_t *eob) {
+    int32_t cul = 0;
+    for (int32_t c = 0; c < *eob; c++) {
+        const int32_t v = quant_coeff[scan[c]];
+        cul += v < 0 ? -v : v;
+        if (cul >= 63) break; /* the clamp below makes the early exit invisible */
+    }
+    cul = cul < 63 ? cul : 63;
+    if (quant_coeff[0] < 0) cul |= 1 << 6;
+    else if (quant_coeff[0] > 0) cul += 2 << 6;
+    return (uint8_t)cul;
+}
+
+/* svt_av1_fwht4x4_c: Codec/transforms.c:3099-3151 (lossless blocks only): the 4-point reversible Walsh-Hadamard, columns then
+ * rows, 64-bit temporaries, outputs scaled by UNIT_QUANT_FACTOR = 4 (transforms.h:25-26).  Output order per pass: a, c, d, b. */
+static void wht4(int64_t a, int64_t b, int64_t c, int64_t d, int64_t o[4]) {
+    a += b;
+    d -= c;
+    const int64_t e = (a - d) >> 1;
+    b = e - b;
+    c = e - c;
+    a -= c;
+    d += b;
+    o[0] = a; o[1] = c; o[2] = d; o[3] = b;
+}
+void orc_fwht4x4(const int16_t *input, int32_t *output, uint32_t stride) {
+    int32_t t[16];
+    int64_t o[4];
+    for (int i = 0; i < 4; i++) { /* column i of the input -> row i of the intermediate */
+        wht4(input[i], input[stride + i], input[2 * stride + i], input[3 * stride + i], o);
+        for (int k = 0; k < 4; k++) t[4 * i + k] = (int32_t)o[k];
+    }
+    for (int i = 0; i < 4; i++) { /* column i of the intermediate -> column i of the output */
+        wht4(t[i], t[4 + i], t[8 + i], t[12 + i], o);
+        for (int k = 0; k < 4; k++) output[4 * k + i] = (int32_t)(o[k] * 4);
+    }
+}
+
+/* get_hvs_modulation_factor: Codec/psy_rd.c:295-307 */
+double orc_hvs_modulation_factor(double psy_rd, int is_islice, uint8_t temporal_layer_index) {
+    if (is_islice) return psy_rd * 0.4;
+    if (temporal_layer_index == 0) return psy_rd * 0.75;
+    if (temporal_layer_index == 1) return psy_rd * 0.9;
+    if (temporal_layer_index == 2) return psy_rd * 0.95;
+    return psy_rd;
+}

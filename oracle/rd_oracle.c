@@ -23,6 +23,7 @@ void     orc_inv_txfm2d_add(const int32_t *, const uint16_t *, int32_t, uint16_t
 int      orc_scan_order(int, int, int16_t *, int16_t *);
 int      orc_tx_size_wide(int);
 int      orc_tx_size_high(int);
+uint8_t  orc_compute_cul_level(const int16_t *, const int32_t *, const uint16_t *);
 
 static const uint8_t k_log_scale[19] = {0, 0, 0, 1, 2, 0, 0, 0, 0, 1, 1, 2, 2, 0, 0, 0, 0, 1, 1}; /* av1_get_tx_scale_tab, full_loop.h:53 */
 
@@ -62,6 +63,7 @@ int orc_rd_batch(const SvtHipRdBatchDesc *d) {
             orc_quantize_b(co, NP, qr->zbin, qr->round, qr->quant, qr->quant_shift, q, dq, qr->dequant, &d->eob[j], scan[kind], qm, iqm, k_log_scale[ts], hbd);
         else
             orc_quantize_fp(co, NP, qr->round_fp, qr->quant_fp, q, dq, qr->dequant, &d->eob[j], scan[kind], qm, iqm, k_log_scale[ts], hbd);
+        if (d->cul_level) d->cul_level[j] = orc_compute_cul_level(scan[kind], q, &d->eob[j]); /* full_loop.c:1832-1836 */
         orc_full_distortion32(co, WP, dq, WP, &d->dist_coeff[2 * (size_t)j], WP, HP);
         for (int r = 0; r < H; r++)
             for (int c = 0; c < W; c++)

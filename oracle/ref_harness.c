@@ -486,6 +486,7 @@ int ref_rd_batch(const SvtHipRdBatchDesc *d) {
         const ScanOrder *so = &av1_scan_orders[ts][tt];
         if (hbd) svt_aom_highbd_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
         else svt_aom_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
+        if (d->cul_level) d->cul_level[j] = svt_av1_compute_cul_level_c(so->scan, q, &d->eob[j]); /* the wrapper's return value, full_loop.c:1836 */
         uint64_t dist[DIST_CALC_TOTAL];
         svt_full_distortion_kernel32_bits(co, WP, dq, WP, dist, WP, HP);
         d->dist_coeff[2 * (size_t)j] = dist[DIST_CALC_RESIDUAL]; d->dist_coeff[2 * (size_t)j + 1] = dist[DIST_CALC_PREDICTION];
@@ -585,3 +586,7 @@ int ref_pyramid(const SvtHipPlaneDesc *full, const SvtHipPlaneDesc *quarter, con
     free(pcs);
     return 0;
 }
+
+/* get_hvs_modulation_factor is not declared in a header every caller includes */
+double get_hvs_modulation_factor(double psy_rd, bool is_islice, uint8_t temporal_layer_index);
+double ref_hvs_modulation_factor(double psy_rd, int is_islice, uint8_t temporal_layer_index) { return get_hvs_modulation_factor(psy_rd, is_islice != 0, temporal_layer_index); }

@@ -155,14 +155,15 @@ class RdBatchDesc(C.Structure):
                 ("src", C.c_void_p), ("pred", C.c_void_p), ("recon", C.c_void_p), ("jobs", C.c_void_p), ("quant_rows", C.c_void_p),
                 ("n_quant_rows", C.c_uint32),
                 ("eob", C.c_void_p), ("satd", C.c_void_p), ("dist_coeff", C.c_void_p), ("three_quad_energy", C.c_void_p), ("sse", C.c_void_p),
-                ("coeff", C.c_void_p), ("qcoeff", C.c_void_p), ("dqcoeff", C.c_void_p), ("qmatrix", C.c_void_p), ("iqmatrix", C.c_void_p)]
+                ("coeff", C.c_void_p), ("qcoeff", C.c_void_p), ("dqcoeff", C.c_void_p), ("qmatrix", C.c_void_p), ("iqmatrix", C.c_void_p),
+                ("cul_level", C.c_void_p)]
 
 
 TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
 TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
 JOB_DTYPE = [("src_offset", "<u4"), ("pred_offset", "<u4"), ("tx_type", "u1"), ("quant_row", "u1"), ("pf_shape", "u1"), ("reserved", "u1")]
 QUANT_ROW_DTYPE = [(n, "<i2", (2,)) for n in ("zbin", "round", "quant", "quant_shift", "round_fp", "quant_fp", "dequant")]
-RD_OUT_FIELDS = [("eob", "<u2", 1), ("satd", "<u4", 1), ("dist_coeff", "<u8", 2), ("three_quad_energy", "<u8", 1), ("sse", "<u8", 1)]
+RD_OUT_FIELDS = [("eob", "<u2", 1), ("satd", "<u4", 1), ("dist_coeff", "<u8", 2), ("three_quad_energy", "<u8", 1), ("sse", "<u8", 1), ("cul_level", "u1", 1)]
 
 
 class BlockJob(C.Structure):

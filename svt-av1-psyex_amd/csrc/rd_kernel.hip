@@ -457,7 +457,8 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     const int     log_scale = c_log_scale[TS];
     const int16_t *iscan    = p.iscan[(tt >= 10) ? ((tt & 1) ? 2 : 1) : 0];
     const uint8_t *qm = (tt < 9) ? p.d.qmatrix : nullptr, *iqm = (tt < 9) ? p.d.iqmatrix : nullptr; // IS_2D_TRANSFORM, full_loop.c:1606-1608
-    uint32_t satd = 0, eob = 0;
+    uint32_t satd = 0, eob = 0, qsum = 0; // qsum: sum of min(|qcoeff|, 63) = svt_av1_compute_cul_level's running sum up to its clamp
+    int32_t  dc_q = 0;                    // lane 0 of a block: the quantized DC coefficient (rc == 0 is its first iteration)
     u64      dres = 0, dpred = 0;
     int32_t *co_out = (p.d.coeff && valid) ? p.d.coeff + (size_t)job * NP : nullptr;
     int32_t *q_out  = (p.d.qcoeff && valid) ? p.d.qcoeff + (size_t)job * NP : nullptr;
@@ -512,6 +513,8 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         }
         const int32_t qs = (qv ^ sign) - sign, dqs = (dq ^ sign) - sign;
         if (qv) { const uint32_t e = (uint32_t)iscan[rc] + 1; eob = e > eob ? e : eob; }
+        qsum += (uint32_t)(qv > 63 ? 63 : qv);
+        if (rc == 0) dc_q = qs;
         const i64 dd = (i64)co - dqs;
         dres += (u64)(dd * dd);
         dpred += (u64)((i64)co * co);
@@ -521,6 +524,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         if (dq_out) dq_out[rc] = dqs;
     }
     satd  = seg_sum_u32<LW>(satd);
+    qsum  = seg_sum_u32<LW>(qsum);
     eob   = seg_max_u32<LW>(eob);
     dres  = seg_sum_u64<LW>(dres);
     dpred = seg_sum_u64<LW>(dpred);
@@ -581,6 +585,9 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         p.d.dist_coeff[2 * (size_t)job + 1] = dpred;
         p.d.three_quad_energy[job] = tq;
         p.d.sse[job]  = sse;
+        // svt_av1_compute_cul_level (full_loop.c:1449-1466): coefficients past eob are zero, so the sum over the scan equals the sum over
+        // the block; set_dc_sign (:1338-1343)
+        if (p.d.cul_level) p.d.cul_level[job] = (uint8_t)((qsum > 63 ? 63 : qsum) | (dc_q < 0 ? 64 : 0)) + (uint8_t)(dc_q > 0 ? 128 : 0);
     }
 }
 

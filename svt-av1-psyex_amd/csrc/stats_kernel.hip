@@ -375,6 +375,32 @@ __global__ void __launch_bounds__(64) satd_kernel(const int32_t *coeff, int n, i
     if (threadIdx.x == 0) *out = acc;
 }
 
+// svt_av1_compute_cul_level (full_loop.c:1449-1466): min(63, sum over the first eob scan positions of |q|) + the DC sign bits.  A lane's terms
+// are clamped to 63 each, which leaves the clamped total unchanged (and keeps the sum far from overflow, like the reference's early exit).
+__global__ void __launch_bounds__(64) cul_level_kernel(const int16_t *scan, const int32_t *q, int eob, uint8_t *out) {
+    uint32_t acc = 0;
+    for (int c = threadIdx.x; c < eob; c += 64) { const int32_t v = q[scan[c]]; const uint32_t a = (uint32_t)(v < 0 ? -v : v); acc += a > 63u ? 63u : a; }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) { const int32_t dc = q[0]; *out = (uint8_t)((acc > 63u ? 63u : acc) + (dc < 0 ? 64u : (dc > 0 ? 128u : 0u))); }
+}
+
+// svt_av1_fwht4x4 (transforms.c:3099-3151): 4-point reversible Walsh-Hadamard on columns, then on the rows of the intermediate; lane i < 4 owns
+// column i in both passes (the second pass reads the transposed intermediate through LDS).  64-bit temporaries like the reference.
+__device__ __forceinline__ void wht4(i64 a, i64 b, i64 c, i64 d, i64 o[4]) {
+    a += b; d -= c;
+    const i64 e = (a - d) >> 1;
+    b = e - b; c = e - c; a -= c; d += b;
+    o[0] = a; o[1] = c; o[2] = d; o[3] = b;
+}
+__global__ void __launch_bounds__(64) fwht4x4_kernel(const int16_t *in, uint32_t stride, int32_t *out) {
+    __shared__ int32_t t[16];
+    const int i = threadIdx.x;
+    i64 o[4];
+    if (i < 4) { wht4(in[i], in[stride + i], in[2 * stride + i], in[3 * stride + i], o); for (int k = 0; k < 4; k++) t[4 * i + k] = (int32_t)o[k]; }
+    __syncthreads();
+    if (i < 4) { wht4(t[i], t[4 + i], t[8 + i], t[12 + i], o); for (int k = 0; k < 4; k++) out[4 * k + i] = (int32_t)(o[k] * 4); }
+}
+
 // ---- coefficient-domain distortion (svt_full_distortion_kernel32_bits_c / _cbf_zero32_bits_c, pic_operators.c:150-222;
 // svt_av1_block_error_c, common_dsp_rtcd.c:79-91): out[0] = sum (coeff - recon)^2 (recon == nullptr: 0), out[1] = sum coeff^2
 // wrap32: svt_av1_block_error_c squares with SQR() on `int` operands -- a 32-bit wrapping product, widened afterwards
@@ -679,6 +705,50 @@ int svt_aom_satd_hip(const int32_t *coeff, int length) {
     leaf_check(ctx, hipMemcpyAsync(&out, base + cb, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return out;
+}
+
+// svt_av1_compute_cul_level (aom_dsp_rtcd.h:904): the prototype carries no array length; scan[0 .. eob) and the coefficients those
+// positions (and position 0) name are what the reference reads, so that is what travels
+uint8_t svt_av1_compute_cul_level_hip(const int16_t *const scan, const int32_t *const quant_coeff, uint16_t *eob) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    const int n = *eob;
+    int       top = 0;
+    for (int c = 0; c < n; c++) top = scan[c] > top ? scan[c] : top;
+    const size_t sb = align256((size_t)(n ? n : 1) * 2), qb = align256((size_t)(top + 1) * 4);
+    uint8_t *base = leaf_scratch(ctx, sb + qb + 256);
+    if (n) leaf_check(ctx, hipMemcpyAsync(base, scan, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(base + sb, quant_coeff, (size_t)(top + 1) * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    hipLaunchKernelGGL(cul_level_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<const int16_t *>(base), reinterpret_cast<const int32_t *>(base + sb), n, base + sb + qb);
+    leaf_check(ctx, hipGetLastError(), "cul_level_kernel launch");
+    uint8_t out = 0;
+    leaf_check(ctx, hipMemcpyAsync(&out, base + sb + qb, 1, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return out;
+}
+
+// svt_av1_fwht4x4 (aom_dsp_rtcd.h:208)
+void svt_av1_fwht4x4_hip(int16_t *input, int32_t *output, uint32_t stride) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    SvtHipContext *ctx = leaf_ctx();
+    hipSetDevice(ctx->device);
+    const size_t ib = align256((3 * (size_t)stride + 4) * 2);
+    uint8_t *base = leaf_scratch(ctx, ib + 256);
+    leaf_check(ctx, hipMemcpyAsync(base, input, (3 * (size_t)stride + 4) * 2, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    hipLaunchKernelGGL(fwht4x4_kernel, dim3(1), dim3(64), 0, ctx->stream, reinterpret_cast<const int16_t *>(base), stride, reinterpret_cast<int32_t *>(base + ib));
+    leaf_check(ctx, hipGetLastError(), "fwht4x4_kernel launch");
+    leaf_check(ctx, hipMemcpyAsync(output, base + ib, 16 * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+// get_hvs_modulation_factor (psy_rd.c:295-307): host arithmetic
+double svt_hip_hvs_modulation_factor(double psy_rd, int is_islice, uint8_t temporal_layer_index) {
+    if (is_islice) return psy_rd * 0.4;
+    if (temporal_layer_index == 0) return psy_rd * 0.75;
+    if (temporal_layer_index == 1) return psy_rd * 0.9;
+    if (temporal_layer_index == 2) return psy_rd * 0.95;
+    return psy_rd;
 }
 
 

@@ -276,3 +276,45 @@ def test_handle_transform_semantics_against_reference(ref):
             energy = int((m ** 2).sum() - (m[:hp, :wp] ** 2).sum()) if suf == "" else 0
             got = a.copy()
             assert fn(p(got)) == energy and np.array_equal(got, want), (w, h, suf)
+
+
+def test_cul_level_fwht_and_hvs_factor(oracle, ref):
+    """The three small members of SURVEY 8a: svt_av1_compute_cul_level_c (full_loop.c:1449), svt_av1_fwht4x4_c (transforms.c:3099),
+    get_hvs_modulation_factor (psy_rd.c:295) -- oracle == reference."""
+    rng = np.random.default_rng(77)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    oracle.orc_compute_cul_level.restype = ref.svt_av1_compute_cul_level_c.restype = C.c_uint8
+    for ts in (0, 2, 3, 5, 12):
+        n = min(TX_W[ts], 32) * min(TX_H[ts], 32)
+        scan, iscan = np.zeros(n, np.int16), np.zeros(n, np.int16)
+        assert oracle.orc_scan_order(ts, 0, p(scan), p(iscan)) == n
+        for trial in range(40):
+            q = np.zeros(n, np.int32)
+            k = int(rng.integers(0, n + 1))
+            mag = int(rng.choice([1, 2, 40, 70, 5000]))
+            q[scan[:k]] = rng.integers(-mag, mag + 1, k)
+            if trial % 5 == 0:
+                q[0] = 0
+            nz = np.flatnonzero(q[scan])
+            eob = np.array([nz[-1] + 1 if len(nz) else 0], np.uint16)
+            assert oracle.orc_compute_cul_level(p(scan), p(q), p(eob)) == ref.svt_av1_compute_cul_level_c(p(scan), p(q), p(eob)), (ts, trial)
+    for trial in range(200):
+        stride = int(rng.integers(4, 12))
+        lim = int(rng.choice([255, 1023, 32767]))
+        src = rng.integers(-lim, lim + 1, 4 * stride).astype(np.int16)
+        if trial < 3:
+            src[:] = (lim, -lim, -32768)[trial]
+        a, b = np.zeros(16, np.int32), np.zeros(16, np.int32)
+        oracle.orc_fwht4x4(p(src), p(a), C.c_uint32(stride))
+        ref.svt_av1_fwht4x4_c(p(src), p(b), C.c_uint32(stride))
+        assert np.array_equal(a, b), trial
+    oracle.orc_hvs_modulation_factor.restype = ref.ref_hvs_modulation_factor.restype = C.c_double
+    from svt_av1_psyex_amd import api
+    L = api.lib()
+    L.svt_hip_hvs_modulation_factor.restype = C.c_double
+    for psy in (0.0, 0.5, 1.0, 1.35, 4.0, 0.1 + 0.2):
+        for isl in (0, 1):
+            for tli in range(7):
+                want = ref.ref_hvs_modulation_factor(C.c_double(psy), isl, tli)
+                assert oracle.orc_hvs_modulation_factor(C.c_double(psy), isl, tli) == want
+                assert L.svt_hip_hvs_modulation_factor(C.c_double(psy), isl, tli) == want  # host arithmetic of libsvthip.so: no GPU involved

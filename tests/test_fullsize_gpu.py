@@ -57,10 +57,12 @@ def test_rd_batch_1080p_tx_type_mix(hip_ctx):
     mix = base.copy()
     mix["tx_type"] = (1 + np.arange(len(mix)) % 15).astype(np.uint8)  # ADST / flip / identity / 1-D types
     mix["quant_row"] = (np.arange(len(mix)) // 7 % 2).astype(np.uint8)
+    mix["pred_offset"] += w * h  # the second evaluation of a block reconstructs into a plane of its own (two copies of the prediction)
     jobs = np.concatenate([base, mix])
-    check_rd(hip_ctx, dict(bit_depth=10, quant_kind=0, tx_size=2, src_stride=w, pred_stride=w), y[2], y[1], jobs, rows, coeffs=True)
+    pred = np.concatenate([y[1], y[1]])
+    check_rd(hip_ctx, dict(bit_depth=10, quant_kind=0, tx_size=2, src_stride=w, pred_stride=w), y[2], pred, jobs, rows, coeffs=True)
     y8 = synth.to_8bit(y)
-    check_rd(hip_ctx, dict(bit_depth=8, quant_kind=1, tx_size=2, src_stride=w, pred_stride=w), y8[2], y8[1], jobs, rows, coeffs=False)
+    check_rd(hip_ctx, dict(bit_depth=8, quant_kind=1, tx_size=2, src_stride=w, pred_stride=w), y8[2], np.concatenate([y8[1], y8[1]]), jobs, rows, coeffs=False)
 
 
 def tiling_jobs(w, h, sizes):

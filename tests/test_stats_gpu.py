@@ -396,3 +396,30 @@ def test_leaf_quantizers(leaf, oracle, tx_size, log_scale):
                         getattr(leaf, ("svt_av1_quantize_fp_hip", "svt_av1_quantize_fp_32x32_hip", "svt_av1_quantize_fp_64x64_hip")[log_scale])(*common)
                     oracle.orc_quantize_fp(p(co), C.c_ssize_t(n), p(t["round_fp"]), p(t["quant_fp"]), p(q2), p(d2), p(t["dequant"]), C.byref(e2), p(scan), m, im, log_scale, hbd)
                     assert e1.value == e2.value and np.array_equal(q1, q2) and np.array_equal(d1, d2), ("fp", hbd, case, pat, use_qm)
+
+
+def test_leaf_cul_level_and_fwht4x4(leaf, oracle):
+    """svt_av1_compute_cul_level_hip / svt_av1_fwht4x4_hip with the reference's prototypes (aom_dsp_rtcd.h:904,208) against the oracle."""
+    rng = np.random.default_rng(78)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    leaf.svt_av1_compute_cul_level_hip.restype = oracle.orc_compute_cul_level.restype = C.c_uint8
+    for ts in (0, 2, 3, 9):
+        n = min(abi.TX_W[ts], 32) * min(abi.TX_H[ts], 32)
+        scan, iscan = np.zeros(n, np.int16), np.zeros(n, np.int16)
+        assert oracle.orc_scan_order(ts, 0, p(scan), p(iscan)) == n
+        for trial in range(12):
+            q = np.zeros(n, np.int32)
+            k = int(rng.integers(0, n + 1)) if trial else 0
+            mag = int(rng.choice([1, 3, 70, 5000]))
+            q[scan[:k]] = rng.integers(-mag, mag + 1, k)
+            nz = np.flatnonzero(q[scan])
+            eob = np.array([nz[-1] + 1 if len(nz) else 0], np.uint16)
+            assert leaf.svt_av1_compute_cul_level_hip(p(scan), p(q), p(eob)) == oracle.orc_compute_cul_level(p(scan), p(q), p(eob)), (ts, trial)
+    for trial in range(24):
+        stride = int(rng.integers(4, 12))
+        lim = int(rng.choice([255, 1023, 32767]))
+        src = rng.integers(-lim, lim + 1, 4 * stride).astype(np.int16)
+        a, b = np.zeros(16, np.int32), np.zeros(16, np.int32)
+        leaf.svt_av1_fwht4x4_hip(p(src), p(a), C.c_uint32(stride))
+        oracle.orc_fwht4x4(p(src), p(b), C.c_uint32(stride))
+        assert np.array_equal(a, b), trial
