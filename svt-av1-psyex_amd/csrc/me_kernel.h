@@ -4,16 +4,14 @@
 #include <stdint.h>
 #include "../../include/svt_hip_me.h"
 
-// Workgroup shape of the ME kernel (tunable at build time): threads per 64x64 block, resident workgroups per CU the
-// grid and the launch bounds are sized for, and the LDS window arena each workgroup owns.
-#ifndef SVT_HIP_ME_THREADS
-#define SVT_HIP_ME_THREADS 256
-#endif
-#ifndef SVT_HIP_ME_WG_PER_CU
-#define SVT_HIP_ME_WG_PER_CU 4
+// Shape of the ME kernel (tunable at build time): one wave per 64x64 block; waves per SIMD the launch bounds plan for
+// (3 -> 168 VGPRs, at most 12 blocks in flight per CU) and the LDS window arena each wave owns (the integer search needs
+// 64 + 2 rows of 96 .. 112 bytes at least: 8 KiB).
+#ifndef SVT_HIP_ME_WAVES_PER_SIMD
+#define SVT_HIP_ME_WAVES_PER_SIMD 3
 #endif
 #ifndef SVT_HIP_ME_WIN_BYTES
-#define SVT_HIP_ME_WIN_BYTES 16384
+#define SVT_HIP_ME_WIN_BYTES 8192
 #endif
 #define SVT_HIP_ME_QUEUES 8 /* one b64 band queue per XCD */
 
@@ -113,9 +111,10 @@ struct MeKernelParams {
 #define SVT_HIP_ME_MAX_PICTURES 16
 #define SVT_HIP_ME_HEADER_BYTES 256 /* sizeof(MeBatchHeader) rounded up: the parameter blocks follow at this offset */
 struct MeBatchHeader {
-    uint32_t  n_pictures, pad;
+    uint32_t  n_pictures, n_slot; // n_slot: the largest number of (list, reference) pairs a picture of the launch searches
     uint32_t  job_base[SVT_HIP_ME_MAX_PICTURES + 1];
     uint32_t  queue_begin[SVT_HIP_ME_QUEUES + 1];
+    uint32_t  cshift, pad; // 1: the source views in LDS keep their even rows only (every search of the launch is row-subsampled)
     uint32_t *queue_head; // SVT_HIP_ME_QUEUES counters, zeroed before launch
 };
 #ifdef __cplusplus

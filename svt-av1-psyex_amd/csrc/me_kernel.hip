@@ -1,22 +1,25 @@
 // me_kernel.hip -- open-loop motion estimation for one picture on gfx950 (MI355X, CDNA4).
 //
-// One persistent workgroup (256 threads = 4 wave64) owns one 64x64 block (b64) at a time and runs the whole
-// per-block pipeline of svt_aom_motion_estimation_b64 (reference: Source/Lib/Codec/motion_estimation.c:3076-3153)
-// on the device: zero-MV SADs, pre-HME, HME level 0/1/2, search-centre selection, reference pruning, the
-// 8x8-based integer search for 85 square PUs, candidate construction and the per-block distortion scalars.
+// ONE WAVE owns one 64x64 block (b64) at a time and runs the whole per-block pipeline of svt_aom_motion_estimation_b64
+// (reference: Source/Lib/Codec/motion_estimation.c:3076-3153) on the device: zero-MV SADs, pre-HME, HME level 0/1/2,
+// search-centre selection, reference pruning, the 8x8-based integer search for 85 square PUs, candidate construction and the
+// per-block distortion scalars.  Workgroups are single waves: there is no workgroup barrier anywhere in the kernel, the
+// stages of a block are ordered by the wave's own program order, and a CU hides the latencies of one block's dependent
+// stages (global loads of the search windows, LDS round trips of the control code) behind the 10+ other blocks resident on it.
 //
 // Mapping to the hardware:
-//   * b64 jobs are pulled from eight band queues in HBM (one per XCD; a workgroup drains the queue of the XCD it
-//     runs on first, so neighbouring blocks -- whose search windows overlap -- share that XCD's L2), then steals.
-//   * every search stages its reference window once into LDS with 16-byte coalesced loads; the source block
-//     lives in LDS (HME) or in registers (integer search).
+//   * persistent waves pull b64 jobs from eight band queues in HBM (one per XCD; a wave drains the queue of the XCD it
+//     runs on first, so neighbouring blocks -- whose search windows overlap -- share that XCD's L2), then steal.
+//   * every search stages its reference window once into the wave's LDS arena with 16-byte coalesced loads; the next
+//     search's window is already in flight (in registers) while the current one is evaluated.  The source block lives in LDS
+//     (HME) or in registers (integer search).
 //   * SADs use v_qsad_pk_u16_u8: one instruction = 4 search positions x 4 pixels; row-subsampled like the
 //     reference (SUB_SAD_SEARCH).  Arg-min keeps the reference's "first minimum in raster order" rule through a
-//     (sad, y, x) lexicographic key, reduced with LDS 64-bit atomic min.
-//   * integer search: wave <-> 4 consecutive search positions, lane <-> one 8x8 PU (quad-tree lane order), 16x16 /
-//     32x32 / 64x64 sums by DPP/shuffle reductions, 85 running bests in registers.
-//   * the data-dependent control logic (search-area sizing, early exits, pruning) is executed by lane 0 between
-//     the parallel phases, on state kept in LDS.
+//     (sad, y, x) lexicographic key, reduced across the wave's lanes.
+//   * integer search: the wave <-> 4 consecutive search positions, lane <-> one 8x8 PU (quad-tree lane order), 16x16 /
+//     32x32 / 64x64 sums by DPP reductions, 85 running bests in registers.
+//   * the data-dependent control logic (search-area sizing, early exits, pruning) runs between the parallel phases on
+//     state kept in the wave's LDS slice; launch parameters are scalar (SGPR) values.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -41,10 +44,9 @@ struct Prof { unsigned long long acc[24], last; };
 
 namespace {
 
-constexpr int kThreads  = SVT_HIP_ME_THREADS;
-constexpr int kWaves    = kThreads / 64;
-constexpr int kMaxReq   = 32;    // searches per batch (4 HME regions x 8 refs)
-constexpr int kWinBytes = SVT_HIP_ME_WIN_BYTES; // LDS window arena
+constexpr int kThreads  = 64;    // one wave per block
+constexpr int kMaxReq   = 32;    // searches per stage (4 HME regions x 8 refs)
+constexpr int kWinBytes = SVT_HIP_ME_WIN_BYTES; // LDS window arena of a wave
 constexpr int kSrc64Pitch = 80, kSrc32Pitch = 48, kSrc16Pitch = 16; // LDS row pitches of the source views: block rows 2 apart land on different banks
 #ifndef SVT_ME_ROWS_PER_SLICE
 #define SVT_ME_ROWS_PER_SLICE 2
@@ -77,35 +79,6 @@ struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
     uint8_t        bw, bh, rs, level; // block width, effective rows, plane rows per block row, source view
     uint8_t        skip_even, pad0;
     int16_t        pad1;
-};
-
-struct __attribute__((aligned(16))) Tile { // a rectangle of a Req whose window fits the LDS arena (carries what staging / evaluation
-                                           // need; users copy it by value: six 16-byte LDS reads instead of a read per field)
-    const uint8_t *g0;     // 16-byte aligned global address of LDS byte 0 of the tile's first row
-    uint32_t stride;
-    uint32_t lds_off;      // byte offset in the arena
-    uint8_t  req, narrow, bw, bh; // request index; block geometry copied from the request
-    uint8_t  rs, level, skip_even, pad;
-    int16_t  x0, y0, w, h; // sub-area of the search area
-    uint16_t pitch;        // LDS row pitch in bytes (multiple of 16)
-    uint16_t shift;        // position x0 sits at LDS byte `shift` of a row
-    uint32_t item0, nitems, ng;
-    uint32_t vec0;         // index of this tile's first 16-byte vector in the batch's flattened staging order
-    uint32_t slices;       // narrow: block rows per position (one item each, ordered slice-major so that the lanes of a
-                           // wave mostly work on different positions and rows 1 apart), else 1
-    float    ng_rcp, h_rcp, vpr_rcp; // rcp_of(ng), rcp_of(h), rcp_of(pitch / 16)
-};
-
-static_assert(sizeof(Tile) % 16 == 0, "Tile is copied as 16-byte vectors");
-// register copy of a tile through whole 16-byte LDS reads (a per-field copy would issue one small LDS read per field)
-union TileRegs {
-    typedef uint32_t V4 __attribute__((ext_vector_type(4)));
-    Tile t;
-    V4   v[sizeof(Tile) / 16];
-    __device__ __forceinline__ TileRegs(const Tile &src) {
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(Tile) / 16); k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(&src) + k); // opaque to load narrowing
-    }
 };
 
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
@@ -141,34 +114,53 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
     uint8_t  l0_req[2][4];
     uint8_t  lvl_req[2][4][2][2];
     uint8_t  c00_req[2][4];
-    // batch machinery
-    int      nreq, ntile, next_req, next_x, next_y, nitems, nvec, cur_tw, cur_th, last, any_narrow;
-    Req      req[kMaxReq];
-    u64      req_key[kMaxReq];
-    Tile     tile[kMaxReq];
-    union { // never live together: batched SAD rounds / integer search
-        uint32_t sadbuf[kMaxReq * kNarrowMaxPos];
-        u64      wave_best[kWaves][85];
+    // the searches of the current stage and their results
+    int      nreq;
+    union { // never live together: the requests of the HME stages and of check_00_center / the integer searches of the probe and main stages
+        Req      req[kMaxReq];
+        struct { MeReq me[8], me_probe[8]; };
     };
+    u64      req_key[kMaxReq];
+    uint32_t sadbuf[kNarrowMaxPos]; // per-position sums of a narrow (row-split) search
     int      nme, nprobe;
-    MeReq    me[8], me_probe[8];
-    uint32_t best_sad[2][4][85];
-    uint32_t best_mv[2][4][85];
     uint32_t me_dist[85];
     uint8_t  cand0[88];  // candidate 0 of every PU (row order), for perform_gm_detection
     uint32_t red[8];
     int      job, tf_exit;
 };
 
-struct Shared {
-    St      st;
-    __attribute__((aligned(16))) uint8_t src64[64 * kSrc64Pitch];
-    __attribute__((aligned(16))) uint8_t src32[32 * kSrc32Pitch];
-    __attribute__((aligned(16))) uint8_t src16[16 * kSrc16Pitch];
-    __attribute__((aligned(16))) uint8_t win[kWinBytes];
+// A wave's LDS slice: St, the three source views, best_sad[n_slot][85] and best_mv[n_slot][85] (MeContext.p_sb_best_sad /
+// p_sb_best_mv of the (list, reference) pairs the launch's pictures search: n_slot = the largest count among them), the window
+// arena.  When every picture of the launch sub-samples both the HME and the integer search (SUB_SAD_SEARCH: every other row),
+// the source views keep their even rows only (cshift = 1): row r of a view lives at row r >> cshift.
+struct LdsLayout { uint32_t src16, src32, src64, bsad, bmv, win, total; };
+__host__ __device__ constexpr LdsLayout lds_layout(int n_slot, int cshift) {
+    LdsLayout l = {};
+    l.src16 = (uint32_t)((sizeof(St) + 15) & ~(size_t)15);
+    l.src32 = l.src16 + (uint32_t)((16 >> cshift) * kSrc16Pitch);
+    l.src64 = l.src32 + (uint32_t)((32 >> cshift) * kSrc32Pitch);
+    l.bsad  = l.src64 + (uint32_t)((64 >> cshift) * kSrc64Pitch);
+    l.bmv   = l.bsad + (uint32_t)n_slot * 85 * 4;
+    l.win   = (l.bmv + (uint32_t)n_slot * 85 * 4 + 15) & ~15u;
+    l.total = l.win + (uint32_t)kWinBytes;
+    return l;
+}
+extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[]; // the wave's LDS slice
+struct Shared { // byte offsets into g_lds (pointers kept in a struct would lose the LDS address space and turn into flat accesses)
+    St       &st;
+    uint32_t  src64, src32, src16, win;
+    int       cshift;
 };
+#define LDS(off) (g_lds + (off))
 
-static_assert(sizeof(Shared) * SVT_HIP_ME_WG_PER_CU <= 160 * 1024, "the planned workgroups per CU must fit the 160 KiB LDS");
+// Orders the wave's own LDS traffic for the compiler: what one lane stored before this point, every lane may load after it.  The
+// hardware executes a wave's LDS instructions in order, so no instruction is needed -- only the compiler must not move memory
+// operations across (a lane reading what another lane wrote is invisible to its single-thread view of the program).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -184,6 +176,7 @@ __device__ __forceinline__ u64 wave_sum64(u64 v) {
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // svt_aom_get_scaled_picture_distance, motion_estimation.c:1239-1243
 __device__ __forceinline__ uint32_t scaled_distance(uint32_t dist) { return (dist * 5) / 8 + ((dist % 8) ? 1 : 0); }
@@ -214,204 +207,30 @@ __device__ __forceinline__ const uint8_t *plane_at(CPlane &pl, int x, int y) {
 __device__ __forceinline__ float rcp_of(uint32_t d) { return __builtin_amdgcn_rcpf((float)d); }
 __device__ __forceinline__ uint32_t div_by_rcp(uint32_t k, float r) { return (uint32_t)(((float)k + 0.5f) * r); }
 
-// LDS row pitch of a staged window: room for the widest read of the last quad, and an odd multiple of 16 bytes so that
-// consecutive rows start 4 (mod 8) banks apart
-__device__ __forceinline__ uint32_t row_pitch(int shift, int w, int bw) {
-    uint32_t p = (uint32_t)(shift + w + bw + 3 + 15) & ~15u;
+// LDS row pitch of a staged window (its first byte is search position x0: the rows are fetched with unaligned 16-byte loads): room for
+// the widest read of the last octet, and an odd multiple of 16 bytes so that consecutive rows start 4 (mod 8) banks apart
+__device__ __forceinline__ uint32_t row_pitch(int w, int bw) {
+    uint32_t p = (uint32_t)(((w + 7) & ~7) + bw + 4 + 15) & ~15u;
     return (p & 16u) ? p : p + 16u;
 }
 
-// bytes of LDS a tile of w x h positions needs (worst-case 16-byte phase when shift < 0)
-__device__ __forceinline__ uint32_t tile_bytes(const Req &r, int shift, int w, int h) {
-    const int sh = shift < 0 ? 15 : shift;
-    return row_pitch(sh, w, r.bw) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1) + 16u; // + slack for the last row's over-read
+// bytes of LDS a tile of w x h positions needs
+__device__ __forceinline__ uint32_t tile_bytes(const Req &r, int w, int h) {
+    return row_pitch(w, r.bw) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
 }
 
-// items per search row of a tile: quads of positions (LDS columns 4g .. 4g+3 from the dword below the first one) for narrow tiles,
-// octets for wide ones
-#ifndef SVT_ME_WIDE_QUADS
-constexpr int kWideShift = 3;
-#else
-constexpr int kWideShift = 2;
-#endif
-#ifdef SVT_ME_NARROW_OCTETS
-constexpr int kNarrowShift = 3;
-#else
-constexpr int kNarrowShift = 2;
-#endif
-__device__ __forceinline__ uint32_t tile_groups(int shift, int w, int narrow) {
-    const uint32_t quads = (uint32_t)((shift & 3) + w + 3) >> 2;
-    return ((narrow ? kNarrowShift : kWideShift) == 2) ? quads : (quads + 1) >> 1;
-}
 
-__device__ __forceinline__ void fill_tile(Tile &t, const Req &r, int req_idx, int x0, int y0, int w, int h, int shift, uint32_t lds_off,
-                                          uint32_t item0, uint32_t vec0) {
-    const int narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
-    t.g0        = r.win + x0 + (long long)y0 * r.stride - shift;
-    t.stride    = r.stride;
-    t.lds_off   = lds_off;
-    t.req       = (uint8_t)req_idx;
-    t.narrow    = (uint8_t)narrow;
-    t.bw = r.bw; t.bh = r.bh; t.rs = r.rs; t.level = r.level; t.skip_even = r.skip_even; t.pad = 0;
-    t.x0 = (int16_t)x0; t.y0 = (int16_t)y0; t.w = (int16_t)w; t.h = (int16_t)h;
-    t.pitch     = (uint16_t)row_pitch(shift, w, r.bw);
-    t.shift     = (uint16_t)shift;
-    t.ng        = tile_groups(shift, w, narrow);
-    t.slices    = narrow ? (uint32_t)(r.bh + kRowsPerSlice - 1) / kRowsPerSlice : 1u;
-    t.item0     = item0;
-    t.nitems    = t.ng * (uint32_t)h * t.slices;
-    t.vec0      = vec0;
-    t.ng_rcp    = rcp_of(t.ng);
-    t.h_rcp     = rcp_of((uint32_t)h);
-    t.vpr_rcp   = rcp_of((uint32_t)t.pitch >> 4);
-}
 
-// lane 0: cut the pending requests into tiles whose reference windows fit the LDS arena.  Every request is
-// cut on a fixed (cur_tw x cur_th) grid chosen so that any of its tiles fits an empty arena.
-__device__ __attribute__((noinline)) void plan_tiles(St &st, bool first) { // the rare path: out of line
-    if (first) { st.next_req = 0; st.next_x = 0; st.next_y = 0; }
-    uint32_t used = 0, items = 0, vecs = 0;
-    int      nt = 0;
-    while (st.next_req < st.nreq && nt < kMaxReq) {
-        const Req &r = st.req[st.next_req];
-        if (st.next_x == 0 && st.next_y == 0) {
-            int tw = r.sa_w, th = r.sa_h;
-            while (th > 1 && tile_bytes(r, -1, tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
-            while (tw > 8 && tile_bytes(r, -1, tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
-            st.cur_tw = tw;
-            st.cur_th = th;
-        }
-        const int x0 = st.next_x, y0 = st.next_y;
-        const int w = imin(st.cur_tw, r.sa_w - x0), h = imin(st.cur_th, r.sa_h - y0);
-        const int shift = (int)((uintptr_t)(r.win + x0) & 15);
-        const uint32_t need = tile_bytes(r, shift, w, h);
-        if (need > kWinBytes - used) break; // flush what is planned; this tile opens the next round
-        Tile &t = st.tile[nt];
-        fill_tile(t, r, st.next_req, x0, y0, w, h, shift, used, items, vecs);
-        vecs += (uint32_t)(t.pitch >> 4) * (uint32_t)(h - 1 + (r.bh - 1) * r.rs + 1);
-        items += t.nitems;
-        used += need;
-        nt++;
-        st.next_x = x0 + w;
-        if (st.next_x >= r.sa_w) {
-            st.next_x = 0;
-            st.next_y = y0 + h;
-            if (st.next_y >= r.sa_h) {
-                st.next_y = 0;
-                st.next_req++;
-            }
-        }
-    }
-    st.ntile  = nt;
-    st.nitems = (int)items;
-    st.nvec   = (int)vecs;
-    st.last   = st.next_req >= st.nreq;
-    int an = 0;
-    for (int i = 0; i < nt; i++) an |= st.tile[i].narrow;
-    st.any_narrow = an;
-}
-
-// wave 0: plan the next round in parallel -- lane i sizes pending request i as ONE tile; an inclusive scan of the byte
-// counts gives the arena offsets and how many leading requests fit.  Returns false (nothing planned) when the cursor is
-// inside a request or the first pending request does not fit the arena in one piece: lane 0 then runs plan_tiles().
-__device__ __forceinline__ bool plan_tiles_wave(St &st, bool first) {
-    const int lane = threadIdx.x;
-    if (!first && (st.next_x != 0 || st.next_y != 0)) return false;
-    const int  nreq = st.nreq;
-    const int  idx  = (first ? 0 : st.next_req) + lane;
-    const bool live = lane < kMaxReq && idx < nreq;
-    uint32_t need = 0, items = 0, vecs = 0;
-    int      shift = 0;
-    if (live) {
-        const Req &r = st.req[idx];
-        shift = (int)((uintptr_t)r.win & 15);
-        const uint32_t pitch = row_pitch(shift, r.sa_w, r.bw);
-        const uint32_t rows  = (uint32_t)(r.sa_h - 1 + (r.bh - 1) * r.rs + 1);
-        const uint32_t ng    = tile_groups(shift, r.sa_w, r.sa_w * r.sa_h <= kNarrowMaxPos);
-        need  = pitch * rows + 16u;
-        items = ng * (uint32_t)r.sa_h * ((r.sa_w * r.sa_h <= kNarrowMaxPos) ? (uint32_t)(r.bh + kRowsPerSlice - 1) / kRowsPerSlice : 1u);
-        vecs  = (pitch >> 4) * rows;
-    }
-    uint32_t pb = need, pi = items, pv = vecs; // inclusive scans: lane j's terms reach the lanes above it
-    const int npend = imin(nreq - (idx - lane), kMaxReq);
-    for (int j = 0; j + 1 < npend; j++) {
-        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)need, j), ti = (uint32_t)__builtin_amdgcn_readlane((int)items, j),
-                       tv = (uint32_t)__builtin_amdgcn_readlane((int)vecs, j);
-        if (lane > j) { pb += tb; pi += ti; pv += tv; }
-    }
-    const bool ok    = live && pb <= (uint32_t)kWinBytes;
-    const u64  mask  = __ballot(ok);
-    const int  count = mask == ~0ull ? 64 : __builtin_ctzll(~mask); // leading requests that fit
-    if (count == 0) return false;
-    const u64 nmask = __ballot(live && (st.req[live ? idx : 0].sa_w * st.req[live ? idx : 0].sa_h <= kNarrowMaxPos)); // requests evaluated by block row
-    if (lane < count) {
-        const Req &r = st.req[idx];
-        fill_tile(st.tile[lane], r, idx, 0, 0, r.sa_w, r.sa_h, shift, pb - need, pi - items, pv - vecs);
-    }
-    if (lane == count - 1) {
-        st.ntile    = count;
-        st.nitems   = (int)pi;
-        st.nvec     = (int)pv;
-        st.next_req = idx + 1;
-        st.next_x   = 0;
-        st.next_y   = 0;
-        st.last     = idx + 1 >= nreq;
-        st.any_narrow = (nmask & ((count >= 64) ? ~0ull : ((1ull << count) - 1ull))) != 0;
-    }
-    return true;
-}
-
-// index of the tile that owns flattened element i, given each lane's tile start (lane j < ntile holds tile j's start)
-__device__ __forceinline__ int tile_of(uint32_t i, uint32_t my_start, int ntile) {
-    int ti = 0;
-    for (int j = 1; j < ntile; j++) ti += (i >= (uint32_t)__builtin_amdgcn_readlane((int)my_start, j)) ? 1 : 0;
-    return ti;
-}
-
-// all threads: copy the tiles' reference windows into the LDS arena with aligned 16-byte loads; the (tile, row, vector)
-// space is flattened so that every thread keeps four independent loads in flight.  Also clears the narrow accumulators.
-__device__ __forceinline__ void stage_tiles(Shared &sh) {
-    St       &st    = sh.st;
-    const int nvec  = st.nvec, ntile = st.ntile;
-    const int lane  = threadIdx.x & 63;
-    const uint32_t my_vec0 = lane < ntile ? st.tile[lane].vec0 : 0xFFFFFFFFu;
-    for (int i = threadIdx.x; i < ntile * kNarrowMaxPos; i += kThreads) st.sadbuf[i] = 0;
-    auto locate = [&](int i, const uint8_t *&g, int &dst) { // global source and LDS destination of flattened vector i
-        const TileRegs tr(st.tile[tile_of((uint32_t)i, my_vec0, ntile)]);
-        const Tile &t = tr.t;
-        const int k = i - (int)t.vec0, vpr = t.pitch >> 4;
-        const int row = (int)div_by_rcp((uint32_t)k, t.vpr_rcp), c = k - row * vpr;
-        g   = t.g0 + (long long)row * t.stride + c * 16;
-        dst = (int)t.lds_off + row * t.pitch + c * 16;
-    };
-    for (int base = threadIdx.x; base < nvec; base += 4 * kThreads) {
-        // out-of-range slots re-load the last vector (harmless) so that the four loads stay unconditional and in registers
-        const int i0 = base, i1 = imin(base + kThreads, nvec - 1), i2 = imin(base + 2 * kThreads, nvec - 1), i3 = imin(base + 3 * kThreads, nvec - 1);
-        const uint8_t *g0, *g1, *g2, *g3;
-        int            d0, d1, d2, d3;
-        locate(i0, g0, d0); locate(i1, g1, d1); locate(i2, g2, d2); locate(i3, g3, d3);
-        // the plane addresses come out of LDS-resident structs, which hides their address space from the compiler: say "global"
-        // (a flat load also counts against the LDS wait counter)
-        typedef uint32_t V4 __attribute__((ext_vector_type(4)));
-        typedef const __attribute__((address_space(1))) V4 GV4;
-        const V4 v0 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g0)), v1 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g1));
-        const V4 v2 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g2)), v3 = *reinterpret_cast<GV4 *>(reinterpret_cast<uintptr_t>(g3));
-        *reinterpret_cast<V4 *>(&sh.win[d0]) = v0;
-        *reinterpret_cast<V4 *>(&sh.win[d1]) = v1;
-        *reinterpret_cast<V4 *>(&sh.win[d2]) = v2;
-        *reinterpret_cast<V4 *>(&sh.win[d3]) = v3;
-    }
-}
 
 __device__ __forceinline__ const uint8_t *src_view(const Shared &sh, int level) {
-    return level == 2 ? sh.src64 : (level == 1 ? sh.src32 : sh.src16);
+    return LDS(level == 2 ? sh.src64 : (level == 1 ? sh.src32 : sh.src16));
 }
 
 // Packed SAD of 4 neighbouring positions over block rows [r0, r1): 4 x u32 sums in out[].  The block's source rows
 // come from LDS (same address in every lane: broadcast reads), the reference rows from the staged window.  NDW = block
 // width in dwords; a whole row is fetched before its qsads issue so the LDS reads overlap instead of serialising.
 template <int NDW>
-__device__ __forceinline__ void quad_sad_rows(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int r0, int r1,
+__device__ __forceinline__ void quad_sad_rows(const uint8_t *src, int src_pitch, int srs, const uint8_t *wrow0, int pitch, int rs, int r0, int r1,
                                               uint32_t out[4]) {
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     constexpr int kRowsPerFlush = 64 / NDW; // 64 qsads x 4 x 255 < 65536: the packed 16-bit lanes cannot overflow before a flush
@@ -419,7 +238,7 @@ __device__ __forceinline__ void quad_sad_rows(const uint8_t *src, int src_pitch,
         const int re = rb + kRowsPerFlush < r1 ? rb + kRowsPerFlush : r1;
         u64       acc = 0;
         for (int r = rb; r < re; r++) {
-            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * rs * src_pitch);
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * srs * src_pitch);
             const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
             uint32_t sv[NDW], wv[NDW + 1];
 #pragma unroll
@@ -436,12 +255,12 @@ __device__ __forceinline__ void quad_sad_rows(const uint8_t *src, int src_pitch,
 }
 
 // block widths without a fixed-size path (right-edge blocks of pictures whose width is not a multiple of 64): rare, out of line
-__device__ __attribute__((noinline)) uint4 quad_sad_generic(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0, int r1) {
+__device__ __attribute__((noinline)) uint4 quad_sad_generic(const uint8_t *src, int src_pitch, int srs, const uint8_t *wrow0, int pitch, int rs, int bw, int r0, int r1) {
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if ((bw & 3) == 0) { // other multiples of 4 (right-edge blocks): generic dword loop
         const int nd = bw >> 2;
         for (int r = r0; r < r1; r++) {
-            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * rs * src_pitch);
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * srs * src_pitch);
             const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
             u64      acc = 0; // at most 16 qsads per row: no overflow within a row
             uint32_t lo  = w[0];
@@ -455,7 +274,7 @@ __device__ __attribute__((noinline)) uint4 quad_sad_generic(const uint8_t *src, 
         }
     } else { // widths that are not a multiple of 4 (right-edge blocks of odd picture widths): byte loop
         for (int r = r0; r < r1; r++) {
-            const uint8_t *s = src + r * rs * src_pitch;
+            const uint8_t *s = src + r * srs * src_pitch;
             const uint8_t *w = wrow0 + r * rs * pitch;
             for (int c = 0; c < bw; c++) {
                 const int sv = s[c];
@@ -467,41 +286,53 @@ __device__ __attribute__((noinline)) uint4 quad_sad_generic(const uint8_t *src, 
     return make_uint4(a0, a1, a2, a3);
 }
 
-__device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0,
+__device__ __forceinline__ void quad_sad(const uint8_t *src, int src_pitch, int srs, const uint8_t *wrow0, int pitch, int rs, int bw, int r0,
                                          int r1, uint32_t out[4]) {
     switch (bw) { // wave-uniform for all practical batches (one block width per HME level)
-    case 16: quad_sad_rows<4>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 32: quad_sad_rows<8>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 64: quad_sad_rows<16>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 8: quad_sad_rows<2>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 4: quad_sad_rows<1>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 16: quad_sad_rows<4>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 32: quad_sad_rows<8>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 64: quad_sad_rows<16>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 8: quad_sad_rows<2>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 4: quad_sad_rows<1>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
     default: break;
     }
-    const uint4 v = quad_sad_generic(src, src_pitch, wrow0, pitch, rs, bw, r0, r1);
+    const uint4 v = quad_sad_generic(src, src_pitch, srs, wrow0, pitch, rs, bw, r0, r1);
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 }
 
 // Wide tiles evaluate 8 neighbouring positions per item: the second quad starts one dword further, so a row costs NDW + 2
 // window reads (and NDW source reads) for 2 * NDW qsads instead of 2 * NDW + 2 (and 2 * NDW).
 template <int NDW>
-__device__ __forceinline__ void oct_sad_rows(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int r0, int r1, uint32_t out[8]) {
+__device__ __forceinline__ void oct_sad_rows(const uint8_t *src, int src_pitch, int srs, const uint8_t *wrow0, int pitch, int rs, int r0, int r1, uint32_t out[8]) {
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int kRowsPerFlush = 64 / NDW;
+    constexpr int CH = NDW > 8 ? 8 : NDW; // a row goes through the registers in chunks of at most 8 dwords (a 64-pixel row at once costs 34 registers)
     for (int rb = r0; rb < r1; rb += kRowsPerFlush) {
         const int re = rb + kRowsPerFlush < r1 ? rb + kRowsPerFlush : r1;
         u64       acc0 = 0, acc1 = 0;
         for (int r = rb; r < re; r++) {
-            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * rs * src_pitch);
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * srs * src_pitch);
             const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
-            uint32_t sv[NDW], wv[NDW + 2];
 #pragma unroll
-            for (int j = 0; j < NDW; j++) sv[j] = s[j];
+            for (int c0 = 0; c0 < NDW; c0 += CH) {
+                uint32_t sv[CH], wv[CH + 2];
+                if constexpr (CH % 4 == 0) { // source rows are 16-byte aligned in LDS: whole-vector reads
 #pragma unroll
-            for (int j = 0; j < NDW + 2; j++) wv[j] = w[j];
+                    for (int j = 0; j < CH; j += 4) {
+                        const uint4 q = *reinterpret_cast<const uint4 *>(s + c0 + j);
+                        sv[j] = q.x; sv[j + 1] = q.y; sv[j + 2] = q.z; sv[j + 3] = q.w;
+                    }
+                } else {
 #pragma unroll
-            for (int j = 0; j < NDW; j++) {
-                acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 1] << 32) | wv[j], sv[j], acc0);
-                acc1 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 2] << 32) | wv[j + 1], sv[j], acc1);
+                    for (int j = 0; j < CH; j++) sv[j] = s[c0 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < CH + 2; j++) wv[j] = w[c0 + j];
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 1] << 32) | wv[j], sv[j], acc0);
+                    acc1 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 2] << 32) | wv[j + 1], sv[j], acc1);
+                }
             }
         }
 #pragma unroll
@@ -511,132 +342,213 @@ __device__ __forceinline__ void oct_sad_rows(const uint8_t *src, int src_pitch, 
     for (int i = 0; i < 8; i++) out[i] = a[i];
 }
 
-__device__ __forceinline__ void oct_sad(const uint8_t *src, int src_pitch, const uint8_t *wrow0, int pitch, int rs, int bw, int r0, int r1, uint32_t out[8]) {
+__device__ __forceinline__ void oct_sad(const uint8_t *src, int src_pitch, int srs, const uint8_t *wrow0, int pitch, int rs, int bw, int r0, int r1, uint32_t out[8]) {
     switch (bw) {
-    case 16: oct_sad_rows<4>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 32: oct_sad_rows<8>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 64: oct_sad_rows<16>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 8: oct_sad_rows<2>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
-    case 4: oct_sad_rows<1>(src, src_pitch, wrow0, pitch, rs, r0, r1, out); return;
+    case 16: oct_sad_rows<4>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 32: oct_sad_rows<8>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 64: oct_sad_rows<16>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 8: oct_sad_rows<2>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
+    case 4: oct_sad_rows<1>(src, src_pitch, srs, wrow0, pitch, rs, r0, r1, out); return;
     default: break;
     }
-    quad_sad(src, src_pitch, wrow0, pitch, rs, bw, r0, r1, out);         // other widths: two quads
-    quad_sad(src, src_pitch, wrow0 + 4, pitch, rs, bw, r0, r1, out + 4);
+    quad_sad(src, src_pitch, srs, wrow0, pitch, rs, bw, r0, r1, out);         // other widths: two quads
+    quad_sad(src, src_pitch, srs, wrow0 + 4, pitch, rs, bw, r0, r1, out + 4);
 }
 
-__device__ __forceinline__ void lds_min_u64(u64 *addr, u64 v) { atomicMin(addr, v); }
+// ---- the search engine: the requests of a stage, one after the other, each as one or more tiles through the LDS arena ----
+typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) V4 GV4; // plane addresses come out of LDS-resident structs, which hides their address
+                                                        // space from the compiler: say "global" (a flat load also counts against the LDS counter)
+constexpr int kVecPerLane = (kWinBytes / 16 + 63) / 64; // 16-byte vectors a lane moves for a full arena
 
-// all threads: evaluate every item of the current plan.  Wide tiles: a thread keeps the running best of the positions
-// it visits and folds it into the request's key; narrow tiles: one item per block row, summed into sadbuf.
-__device__ __forceinline__ void eval_items(Shared &sh) {
-    St       &st     = sh.st;
-    const int nitems = st.nitems, ntile = st.ntile;
-    const int lane   = threadIdx.x & 63;
-    const uint32_t my_item0 = lane < ntile ? st.tile[lane].item0 : 0xFFFFFFFFu;
-    int cur_req = -1;
-    u64 cur_best = ~0ull;
-    for (int it = threadIdx.x; it < nitems; it += kThreads) {
-        const int   ti = tile_of((uint32_t)it, my_item0, ntile);
-        const TileRegs tr(st.tile[ti]);
-        const Tile &t  = tr.t;
-        uint32_t    k  = (uint32_t)it - t.item0;
-        const uint32_t q = div_by_rcp(k, t.ng_rcp);
-        const int   g = (int)(k - q * t.ng);
-        const int   slice = t.narrow ? (int)div_by_rcp(q, t.h_rcp) : 0, y = (int)q - slice * t.h;
-        const int   ysearch = t.y0 + y;
-        if (t.skip_even && !(ysearch & 1)) continue;
-        // the quad (octet, for wide tiles) covers LDS columns col0 .. col0+3 (+7) of the tile's rows; tile-relative x = column - shift
-        const int col0 = (t.shift & ~3) + (t.narrow ? (1 << kNarrowShift) : (1 << kWideShift)) * g;
-        const int xq   = col0 - t.shift;
-        const uint8_t *wrow0 = &sh.win[t.lds_off + y * t.pitch + col0];
-        const uint8_t *src   = src_view(sh, t.level);
-        const int      sp    = (t.level == 2) ? kSrc64Pitch : (t.level == 1 ? kSrc32Pitch : kSrc16Pitch);
-        uint32_t       s4[8];
-        if (t.narrow) {
-            if (kNarrowShift == 3) oct_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, (int)t.bh), s4);
-            else quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, (int)t.bh), s4);
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); } // wave-uniform value -> SGPR
+__device__ __forceinline__ const uint8_t *uni_ptr(const uint8_t *p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    return reinterpret_cast<const uint8_t *>(((uintptr_t)uni((uint32_t)(a >> 32)) << 32) | uni((uint32_t)a));
+}
+
+// minimum over the wave's 64 lanes, in every lane's return value (SGPR): butterfly inside the 16-lane rows by DPP (min is idempotent, so the
+// mirror patterns serve), two row broadcasts, lane 63 holds the result -- no LDS traffic
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define SVT_MIN_DPP(ctrl, rmask) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false); v = t_ < v ? t_ : v; }
+    SVT_MIN_DPP(0xB1, 0xF)  // quad_perm [1,0,3,2]
+    SVT_MIN_DPP(0x4E, 0xF)  // quad_perm [2,3,0,1]
+    SVT_MIN_DPP(0x141, 0xF) // row_half_mirror
+    SVT_MIN_DPP(0x140, 0xF) // row_mirror
+    SVT_MIN_DPP(0x142, 0xA) // row_bcast:15 -> rows 1, 3
+    SVT_MIN_DPP(0x143, 0xC) // row_bcast:31 -> rows 2, 3
+#undef SVT_MIN_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// the wave's smallest (sad, pos) pair as sad << 32 | pos -- the reference's "first minimum in raster order": the smallest SAD, then among
+// its lanes the smallest position word (y << 16 | x); ~0 when no lane holds a result
+__device__ __forceinline__ u64 wave_min_key(uint32_t sad, uint32_t pos) {
+    const uint32_t smin = wave_min_u32(sad);
+    const uint32_t pmin = wave_min_u32(sad == smin ? pos : 0xFFFFFFFFu);
+    return ((u64)smin << 32) | pmin;
+}
+
+// One rectangle of a request's search area whose reference window fits the arena.  Every field is wave-uniform.
+struct TileGeo {
+    const uint8_t *g0;     // global address of the window's first sample (search position (x0, y0), block row 0): LDS byte 0 of the tile
+    uint32_t stride;
+    int      req;          // request index, -1: no tile
+    int      x0, y0, w, h; // sub-area of the search area
+    int      pitch;        // LDS row pitch (multiple of 16)
+    int      nvec;         // 16-byte vectors of the window: (pitch / 16) * rows, rows contiguous in LDS
+    int      last;         // last tile of its request
+    int      bw, bh, rs, level, skip_even, narrow;
+    int      kd, km;       // 64 = kd * (pitch / 16) + km: how (row, vector) advance from one 64-vector pass to the next
+};
+
+// Cursor over the tiles of st.req[0 .. nreq): a request is cut on a fixed (tw x th) grid chosen so that any of its tiles fits the arena
+struct TileCursor { int req, x, y, tw, th; };
+
+__device__ __forceinline__ TileGeo next_tile(const St &st, int nreq, TileCursor &c) {
+    TileGeo t;
+    t.req = -1;
+    if (c.req >= nreq) return t;
+    const Req &rq = st.req[c.req];
+    Req r;
+    r.win = uni_ptr(rq.win); r.stride = uni(rq.stride);
+    r.sa_w = (int16_t)uni((uint32_t)rq.sa_w); r.sa_h = (int16_t)uni((uint32_t)rq.sa_h);
+    r.bw = (uint8_t)uni(rq.bw); r.bh = (uint8_t)uni(rq.bh); r.rs = (uint8_t)uni(rq.rs); r.level = (uint8_t)uni(rq.level); r.skip_even = (uint8_t)uni(rq.skip_even);
+    if (c.x == 0 && c.y == 0) {
+        int tw = r.sa_w, th = r.sa_h;
+        while (th > 1 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
+        while (tw > 8 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
+        c.tw = tw; c.th = th;
+    }
+    const int x0 = c.x, y0 = c.y, w = imin(c.tw, r.sa_w - x0), h = imin(c.th, r.sa_h - y0);
+    t.g0 = r.win + x0 + (long long)y0 * r.stride; t.stride = r.stride; t.req = c.req;
+    t.x0 = x0; t.y0 = y0; t.w = w; t.h = h;
+    t.pitch = (int)row_pitch(w, r.bw);
+    const int vpr = t.pitch >> 4;
+    t.nvec  = vpr * (h - 1 + (r.bh - 1) * r.rs + 1);
+    t.bw = r.bw; t.bh = r.bh; t.rs = r.rs; t.level = r.level; t.skip_even = r.skip_even;
+    t.narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
+    t.kd = (int)div_by_rcp(64u, rcp_of((uint32_t)vpr)); t.km = 64 - t.kd * vpr;
+    c.x = x0 + w;
+    if (c.x >= r.sa_w) { c.x = 0; c.y = y0 + h; }
+    t.last = 0;
+    if (c.y >= r.sa_h) { c.y = 0; c.req++; t.last = 1; }
+    return t;
+}
+
+// the tile's window, global -> registers: lane l owns vectors l, l + 64, ... of the flattened (row, vector) space.  The rows start at
+// an arbitrary byte: unaligned 16-byte loads (position x0 lands on LDS byte 0 of its row, so a tile has no dead leading positions)
+typedef uint32_t V4U __attribute__((ext_vector_type(4), aligned(1)));
+typedef const __attribute__((address_space(1))) V4U GV4U;
+__device__ __forceinline__ void tile_load(const TileGeo &t, V4 (&v)[kVecPerLane]) {
+    const int lane = threadIdx.x, vpr = t.pitch >> 4;
+    int row = (int)div_by_rcp((uint32_t)lane, rcp_of((uint32_t)vpr)), c = lane - row * vpr; // vector `lane`; later passes advance by (kd, km)
 #pragma unroll
-            for (int i = 0; i < (1 << kNarrowShift); i++) {
-                const int x = xq + i;
-                if (x >= 0 && x < t.w) atomicAdd(&st.sadbuf[ti * kNarrowMaxPos + y * t.w + x], s4[i]);
-            }
-        } else {
-            if ((int)t.req != cur_req) {
-                if (cur_best != ~0ull) lds_min_u64(&st.req_key[cur_req], cur_best);
-                cur_req  = t.req;
-                cur_best = ~0ull;
-            }
-            if (kWideShift == 3) oct_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, 0, t.bh, s4);
-            else quad_sad(src, sp, wrow0, t.pitch, t.rs, t.bw, 0, t.bh, s4);
+    for (int j = 0; j < kVecPerLane; j++)
+        if (j * 64 < t.nvec) { // uniform
+            // lanes past the end re-load the last row's vector c (harmless; the load stays unconditional)
+            const int rr = imin(row, (t.nvec - 1) / vpr);
+            const V4U q = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(t.g0 + (long long)rr * t.stride + c * 16));
+            v[j] = V4{q.x, q.y, q.z, q.w};
+            row += t.kd; c += t.km;
+            if (c >= vpr) { c -= vpr; row++; }
+        }
+}
+__device__ __forceinline__ void tile_store(const Shared &sh, const TileGeo &t, const V4 (&v)[kVecPerLane]) {
+    const int lane = threadIdx.x;
 #pragma unroll
-            for (int i = 0; i < (1 << kWideShift); i++) {
-                const int x = xq + i;
-                if (x >= 0 && x < t.w) {
-                    const u64 key = ((u64)s4[i] << 32) | ((u64)(uint32_t)ysearch << 16) | (uint32_t)(t.x0 + x);
-                    cur_best = key < cur_best ? key : cur_best;
-                }
+    for (int j = 0; j < kVecPerLane; j++)
+        if (j * 64 < t.nvec && lane + j * 64 < t.nvec) *reinterpret_cast<V4 *>(&LDS(sh.win)[(lane + j * 64) * 16]) = v[j];
+}
+
+// every position of the tile in the arena; returns the tile's best key (sad << 32 | y << 16 | x), ~0 when no position was evaluated
+__device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t) {
+    St            &st   = sh.st;
+    const int      lane = threadIdx.x;
+    const uint8_t *src  = src_view(sh, t.level);
+    const uint8_t *win  = LDS(sh.win);
+    const int      sp   = (t.level == 2) ? kSrc64Pitch : (t.level == 1 ? kSrc32Pitch : kSrc16Pitch);
+    const int      srs  = t.rs >> sh.cshift; // source row step: the views keep every (1 << cshift)-th row
+    uint32_t bsad_ = 0xFFFFFFFFu, bpos_ = 0xFFFFFFFFu;
+    if (!t.narrow) { // lane <-> 8 neighbouring positions of one search row, the whole block
+        const int   ng = (t.w + 7) >> 3, nitems = ng * t.h;
+        const float ng_rcp = rcp_of((uint32_t)ng);
+        // A lane visits its positions in raster order, so its first minimum is the minimum of (sad << 12 | visit number): one 32-bit key
+        // (sad < 2^20: 64 x 64 x 255; at most 512 items x 8 positions per lane)
+        uint32_t best = 0xFFFFFFFFu;
+        int      seq  = 0;
+        for (int it = lane; it < nitems; it += kThreads, seq += 8) {
+            const int y = (int)div_by_rcp((uint32_t)it, ng_rcp), g = it - y * ng;
+            if (t.skip_even && !((t.y0 + y) & 1)) continue;
+            uint32_t s8[8];
+            oct_sad(src, sp, srs, win + y * t.pitch + 8 * g, t.pitch, t.rs, t.bw, 0, t.bh, s8);
+            uint32_t k[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) k[i] = (s8[i] << 12) + (uint32_t)i;
+            if (t.w & 7) { // uniform: only then an octet can hang over the end of the search row
+#pragma unroll
+                for (int i = 0; i < 8; i++) k[i] = (8 * g + i < t.w) ? k[i] : 0xFFFFF000u;
             }
+            const uint32_t m = umin(umin(umin(k[0], k[1]), k[2]), umin(umin(umin(k[3], k[4]), k[5]), umin(k[6], k[7]))); // v_min3_u32
+            const uint32_t cand = m + (uint32_t)seq;
+            best = cand < best ? cand : best;
+        }
+        if ((best >> 12) != 0xFFFFFu) { // decode the visit number: iteration, position in the octet
+            const int sq = (int)(best & 0xFFFu), it = lane + (sq >> 3) * kThreads;
+            const int y = (int)div_by_rcp((uint32_t)it, ng_rcp), g = it - y * ng;
+            bsad_ = best >> 12;
+            bpos_ = ((uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + 8 * g + (sq & 7));
+        }
+    } else { // few positions: lane <-> 4 positions x kRowsPerSlice block rows, summed per position in LDS
+        if (lane < kNarrowMaxPos) st.sadbuf[lane] = 0;
+        wave_sync();
+        const int   ng = (t.w + 3) >> 2, slices = (t.bh + kRowsPerSlice - 1) / kRowsPerSlice, nitems = ng * t.h * slices;
+        const float ng_rcp = rcp_of((uint32_t)ng), h_rcp = rcp_of((uint32_t)t.h);
+        for (int it = lane; it < nitems; it += kThreads) {
+            const int q = (int)div_by_rcp((uint32_t)it, ng_rcp), g = it - q * ng;
+            const int slice = (int)div_by_rcp((uint32_t)q, h_rcp), y = q - slice * t.h;
+            if (t.skip_even && !((t.y0 + y) & 1)) continue;
+            uint32_t  s4[4];
+            quad_sad(src, sp, srs, win + y * t.pitch + 4 * g, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, t.bh), s4);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * g + i < t.w) atomicAdd(&st.sadbuf[y * t.w + 4 * g + i], s4[i]);
+        }
+        wave_sync();
+        if (lane < t.w * t.h) {
+            const int y = (int)(((float)lane + 0.5f) * __frcp_rn((float)t.w)), x = lane - y * t.w; // exact: w, lane <= 32
+            if (!(t.skip_even && !((t.y0 + y) & 1))) { bsad_ = st.sadbuf[lane]; bpos_ = ((uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + x); }
         }
     }
-    if (cur_best != ~0ull) lds_min_u64(&st.req_key[cur_req], cur_best);
+    return wave_min_key(bsad_, bpos_);
 }
 
-// all threads: fold the narrow tiles' sums into their requests' keys -- 32 lanes per tile, one lane per position
-__device__ __forceinline__ void eval_keys(Shared &sh) {
-    St       &st    = sh.st;
-    const int ntile = st.ntile;
-    for (int i = threadIdx.x; i < ntile * kNarrowMaxPos; i += kThreads) {
-        const int   tj = i / kNarrowMaxPos, pos = i % kNarrowMaxPos;
-        const TileRegs tr(st.tile[tj]);
-        const Tile &t  = tr.t;
-        u64         key = ~0ull;
-        if (t.narrow && pos < t.w * t.h) {
-            const int y = (int)(((float)pos + 0.5f) * __frcp_rn((float)t.w)), x = pos - y * t.w; // exact: w, pos <= 32
-            if (!(t.skip_even && !((t.y0 + y) & 1))) key = ((u64)st.sadbuf[i] << 32) | ((u64)(uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + x);
-        }
-#pragma unroll
-        for (int o = kNarrowMaxPos / 2; o >= 1; o >>= 1) {
-            const u64 other = (u64)__shfl_xor((unsigned long long)key, o, 64);
-            key = other < key ? other : key;
-        }
-        if (pos == 0 && key != ~0ull) lds_min_u64(&st.req_key[t.req], key);
-    }
-}
-
-// wave 0: plan the next round of the pending requests (first: also reset the requests' keys)
-__device__ __forceinline__ void plan_round(St &st, bool first) {
-    if (first && (int)threadIdx.x < st.nreq) st.req_key[threadIdx.x] = (0xffffffull << 32) | 0xffffffffull;
-    const bool planned = plan_tiles_wave(st, first); // the serial planner only handles requests that must be cut into tiles
-    if (!planned && threadIdx.x == 0) plan_tiles(st, first);
-}
-
-// all threads: run st.req[0 .. nreq) (nreq >= 1) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x),
-// or the initial (0xffffff << 32 | 0xffffffff) when no position was evaluated.  The FIRST round has been planned by
-// wave 0 right behind its pushes (plan_round(st, true)) and published by the caller's barrier; on return every thread may
-// read the keys.
+// The wave runs st.req[0 .. nreq) (nreq >= 1) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x), or
+// (0xffffff << 32 | 0xffffffff) when no position was evaluated.  While a tile is evaluated out of the arena, the next tile's
+// window is already on its way into registers.
 __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
-    St &st = sh.st;
-    for (bool first = true;; first = false) {
-        PROF(23);
-        if (!first) {
-            if (threadIdx.x < 64) plan_round(st, false);
-            __syncthreads();
-        }
-        PROF(17);
-        const bool last = st.last, any_narrow = st.any_narrow; // stable until the next round's plan, which starts after this round's final barrier
-        stage_tiles(sh);
-        __syncthreads();
+    St        &st   = sh.st;
+    const int  nreq = (int)uni((uint32_t)st.nreq);
+    TileCursor cur  = {0, 0, 0, 0, 0};
+    V4         v[kVecPerLane];
+    TileGeo    t = next_tile(st, nreq, cur);
+    tile_load(t, v);
+    u64 key = (0xffffffull << 32) | 0xffffffffull;
+    PROF(17);
+    while (t.req >= 0) {
+        tile_store(sh, t, v);
+        wave_sync();
         PROF(18);
-        eval_items(sh);
-        PROF(21);
-        __syncthreads();
-        PROF(22);
-        if (any_narrow) { // uniform; rounds of wide searches only have folded their keys already
-            eval_keys(sh);
-            __syncthreads();
+        const TileGeo nx = next_tile(st, nreq, cur);
+        if (nx.req >= 0) tile_load(nx, v);
+        const u64 k = tile_eval(sh, t);
+        key = k < key ? k : key;
+        if (t.last) {
+            if (threadIdx.x == 0) st.req_key[t.req] = key;
+            key = (0xffffffull << 32) | 0xffffffffull;
         }
-        PROF(19);
-        if (last) break;
+        wave_sync(); // the arena is free again
+        PROF(21);
+        t = nx;
     }
 }
 
@@ -706,7 +618,7 @@ __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
     best        = k < best ? k : best;
 }
 
-// all threads: the window whose top-left sample is pix0 displaced by (wx0, wy0), sample by sample, coordinates clamped into the
+// the wave: the window whose top-left sample is pix0 displaced by (wx0, wy0), sample by sample, coordinates clamped into the
 // padded plane.  Rare (see run_me_searches): kept out of line so that it costs the common path no registers.
 __device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const MeReq &m, int wx0, int wy0, int pitch, int rows) {
     for (int i = threadIdx.x; i < pitch * rows; i += kThreads) {
@@ -716,11 +628,10 @@ __device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const MeRe
     }
 }
 
-// all threads: integer search for the refs in st.me[0..nme).  `merge` semantics follow the reference: strict
+// the wave: integer search for the refs in list[0 .. count).  `merge` semantics follow the reference: strict
 // `<` against what is already in best_sad (initial MAX_SAD_VALUE, or the probe's result).
-__device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count) {
-    St       &st   = sh.st;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count, uint32_t *bsad, uint32_t *bmv, int r0n) {
+    const int lane = threadIdx.x;
     const int sub  = (p.cfg.me_search_method == 0);
     const int nrow = sub ? 4 : 8, rstep = sub ? 2 : 1;
     int       bx, by;
@@ -729,30 +640,38 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
     uint32_t s[8][2];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int row = by * 8 + (k < nrow ? k * rstep : 0);
-        const uint32_t *sp = reinterpret_cast<const uint32_t *>(&sh.src64[row * kSrc64Pitch + bx * 8]);
+        const int row = (by * 8 + (k < nrow ? k * rstep : 0)) >> sh.cshift;
+        const uint32_t *sp = reinterpret_cast<const uint32_t *>(&LDS(sh.src64)[row * kSrc64Pitch + bx * 8]);
         s[k][0] = sp[0];
         s[k][1] = sp[1];
     }
     for (int mi = 0; mi < count; mi++) {
-        const MeReq m = list[mi];
+        MeReq m;
+        { // uniform: through SGPRs
+            const MeReq &mm = list[mi];
+            m.pix0 = uni_ptr(mm.pix0); m.stride = uni(mm.stride);
+            m.ox = (int16_t)uni((uint32_t)mm.ox); m.oy = (int16_t)uni((uint32_t)mm.oy); m.sa_w = (int16_t)uni((uint32_t)mm.sa_w); m.sa_h = (int16_t)uni((uint32_t)mm.sa_h);
+            m.li = (uint8_t)uni(mm.li); m.ri = (uint8_t)uni(mm.ri); m.probe = 0; m.pad = 0;
+            m.min_x = (int16_t)uni((uint32_t)mm.min_x); m.max_x = (int16_t)uni((uint32_t)mm.max_x); m.min_y = (int16_t)uni((uint32_t)mm.min_y); m.max_y = (int16_t)uni((uint32_t)mm.max_y);
+        }
         u64 b8 = ~0ull, b16 = ~0ull, b32 = ~0ull, b64 = ~0ull;
         // tile the search area by rows (and columns) so that the window fits the arena
         const int W = m.sa_w, H = m.sa_h;
         int       tw = W, th = H;
         auto me_pitch = [](int shift, int ww) { return ((shift + ww - 1 + 64 + 15) & ~15) + 16; };
-        auto wbytes = [&](int ww, int hh) { return (uint32_t)me_pitch(15, ww) * (uint32_t)(hh - 1 + 64); };
+        auto wbytes = [&](int ww, int hh) { return (uint32_t)me_pitch(0, ww) * (uint32_t)(hh - 1 + 64); };
         while (th > 1 && wbytes(tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
         while (tw > 8 && wbytes(tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
         for (int y0 = 0; y0 < H; y0 += th)
             for (int x0 = 0; x0 < W; x0 += tw) {
                 const int w = imin(tw, W - x0), h = imin(th, H - y0);
                 const uint8_t *gwin  = m.pix0 + (m.ox + x0) + (long long)(m.oy + y0) * m.stride;
-                const int      shift = (int)((uintptr_t)gwin & 15);
+                const int      shift = 0; // the rows are fetched with unaligned 16-byte loads: position x0 sits on LDS byte 0 of its row
                 const int pitch = me_pitch(shift, w); // 16-byte rows; same formula as the tile sizing above
                 const int rows        = h - 1 + 64;
                 const int vec_per_row = pitch >> 4;
-                __syncthreads(); // previous tile fully consumed
+                const float vpr_rcp   = rcp_of((uint32_t)vec_per_row);
+                wave_sync(); // previous tile fully consumed
                 // The reference's 1-point probe uses the unclipped search centre (motion_estimation.c:1391-1406): a centre far outside
                 // the picture would take these reads past the padded plane (undefined in the reference; a fault here).  Such a tile
                 // -- uniform test -- is staged sample by sample with coordinates clamped to the plane's edge instead.
@@ -760,21 +679,31 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                 // carry that much slack around every row, pictures.hip.)
                 const int wx0 = m.ox + x0 - shift, wy0 = m.oy + y0;
                 if (m.ox + x0 >= m.min_x && m.ox + x0 + w - 1 + 63 <= m.max_x && wy0 >= m.min_y && wy0 + rows - 1 <= m.max_y) {
-                    for (int i = threadIdx.x; i < vec_per_row * rows; i += kThreads) {
-                        const int row = i / vec_per_row, c = i - row * vec_per_row;
-                        typedef uint32_t V4 __attribute__((ext_vector_type(4)));
-                        const V4 v = *reinterpret_cast<const __attribute__((address_space(1))) V4 *>(reinterpret_cast<uintptr_t>(gwin - shift + (long long)row * m.stride + c * 16)); // global, not flat
-                        *reinterpret_cast<V4 *>(&sh.win[row * pitch + c * 16]) = v;
+                    const int nvec = vec_per_row * rows;
+                    for (int base = lane; base < nvec; base += 4 * kThreads) { // four independent loads in flight per lane
+                        int  k[4];
+                        V4   v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            k[j] = imin(base + j * kThreads, nvec - 1);
+                            const int row = (int)div_by_rcp((uint32_t)k[j], vpr_rcp), c = k[j] - row * vec_per_row;
+                            const V4U q4 = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(gwin + (long long)row * m.stride + c * 16));
+                            v[j] = V4{q4.x, q4.y, q4.z, q4.w};
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) *reinterpret_cast<V4 *>(&LDS(sh.win)[k[j] * 16]) = v[j];
                     }
                 } else {
-                    stage_clamped(sh.win, m, wx0, wy0, pitch, rows);
+                    stage_clamped(LDS(sh.win), m, wx0, wy0, pitch, rows);
                 }
-                __syncthreads();
+                wave_sync();
                 const int ng = ((shift & 3) + w + 3) >> 2;
-                for (int q = wave; q < ng * h; q += kWaves) {
+                // inside a tile the positions come in raster order: a strict `<` on the SAD keeps the first minimum; tiles merge by (sad, position)
+                uint32_t t8 = ~0u, t16 = ~0u, t32 = ~0u, t64 = ~0u, o8 = ~0u, o16 = ~0u, o32 = ~0u, o64 = ~0u;
+                for (int q = 0; q < ng * h; q++) { // uniform: the wave <-> one quad of positions
                     const int y = q / ng, g = q - y * ng;
                     const int col0 = (shift & ~3) + 4 * g, xq = col0 - shift;
-                    const uint8_t *wp = &sh.win[(y + by * 8) * pitch + col0 + bx * 8];
+                    const uint8_t *wp = &LDS(sh.win)[(y + by * 8) * pitch + col0 + bx * 8];
                     u64 acc = 0;
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
@@ -795,29 +724,35 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                         const uint32_t v64 = sum64_of_rows(v32);
                         if (x >= 0 && x < w) { // wave-uniform
                             const uint32_t ord = (uint32_t)((y0 + y) * W + (x0 + x));
-                            upd(b8, v8, ord); upd(b16, v16, ord); upd(b32, v32, ord); upd(b64, v64, ord);
+                            if (v8 < t8) { t8 = v8; o8 = ord; }
+                            if (v16 < t16) { t16 = v16; o16 = ord; }
+                            if (v32 < t32) { t32 = v32; o32 = ord; }
+                            if (v64 < t64) { t64 = v64; o64 = ord; }
                         }
                     }
                 }
+                if (t8 != ~0u) upd(b8, t8, o8);
+                if (t16 != ~0u) upd(b16, t16, o16);
+                if (t32 != ~0u) upd(b32, t32, o32);
+                if (t64 != ~0u) upd(b64, t64, o64);
             }
-        // per-wave bests -> LDS, PU index in the reference's n_idx order: 0 = 64x64, 1..4, 5..20, 21..84
-        st.wave_best[wave][21 + lane] = b8;
-        if ((lane & 3) == 0) st.wave_best[wave][5 + (lane >> 2)] = b16;
-        if ((lane & 15) == 0) st.wave_best[wave][1 + (lane >> 4)] = b32;
-        if (lane == kLane64) st.wave_best[wave][0] = b64;
-        __syncthreads();
-        for (int n = threadIdx.x; n < 85; n += kThreads) {
-            u64 k = st.wave_best[0][n];
-            for (int wv = 1; wv < kWaves; wv++) k = st.wave_best[wv][n] < k ? st.wave_best[wv][n] : k;
+        // the wave's bests -> this reference's rows of best_sad / best_mv, PU index in the reference's n_idx order: 0 = 64x64, 1..4, 5..20, 21..84.
+        // Each PU has one owner lane, so the compare-and-store below is race-free.
+        uint32_t *rs_ = bsad + ((m.li ? r0n : 0) + m.ri) * 85, *rm_ = bmv + ((m.li ? r0n : 0) + m.ri) * 85;
+        auto merge = [&](int n, u64 k) {
             const uint32_t sad = (uint32_t)(k >> 32);
-            if (k != ~0ull && sad < st.best_sad[m.li][m.ri][n]) {
+            if (k != ~0ull && sad < rs_[n]) {
                 const uint32_t ord = (uint32_t)k;
                 const int      yy = (int)(ord / (uint32_t)W), xx = (int)(ord - (uint32_t)yy * (uint32_t)W);
-                st.best_sad[m.li][m.ri][n] = sad;
-                st.best_mv[m.li][m.ri][n]  = ((uint32_t)(m.oy + yy) << 16) | (uint16_t)(m.ox + xx);
+                rs_[n] = sad;
+                rm_[n] = ((uint32_t)(m.oy + yy) << 16) | (uint16_t)(m.ox + xx);
             }
-        }
-        __syncthreads();
+        };
+        merge(21 + lane, b8);
+        if ((lane & 3) == 0) merge(5 + (lane >> 2), b16);
+        if ((lane & 15) == 0) merge(1 + (lane >> 4), b32);
+        if (lane == kLane64) merge(0, b64);
+        wave_sync();
     }
 }
 
@@ -908,22 +843,25 @@ __device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy) 
 // =================================================================================================
 // The kernel
 // =================================================================================================
-// the wave that runs a block's serial control code asks for issue priority over the evaluation waves of the other resident workgroups
-// (measured: -1 % ME time at priority 2 or 3; the output phases did not gain)
+// a wave in the control code between two searches asks for issue priority over the waves that are evaluating
 #ifndef SVT_ME_CTRL_PRIO
 #define SVT_ME_CTRL_PRIO 2
 #endif
 #define CTRL_PRIO(x) __builtin_amdgcn_s_setprio(x)
 
-extern "C" __global__ void __launch_bounds__(SVT_HIP_ME_THREADS, (SVT_HIP_ME_WG_PER_CU * (SVT_HIP_ME_THREADS / 64) + 3) / 4)
+extern "C" __global__ void __launch_bounds__(64, SVT_HIP_ME_WAVES_PER_SIMD)
 svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-    Shared &sh = *reinterpret_cast<Shared *>(smem_raw);
-    St     &st = sh.st;
+    St     &st = *reinterpret_cast<St *>(g_lds);
     // launch parameters: read-only, uniform addresses -> scalar loads through the constant cache, values in SGPRs
     typedef const SVT_CONST_AS MeBatchHeader CHeader;
     CHeader  &hdr = *(CHeader *)ghdr;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x; // the lane: a workgroup is one wave
+    // MeContext.p_sb_best_sad / p_sb_best_mv rows of the (list, reference) pairs in use, behind the fixed part of the LDS slice
+    const int       cshift = (int)hdr.cshift;
+    const LdsLayout lay    = lds_layout((int)hdr.n_slot, cshift);
+    uint32_t *const bsad = reinterpret_cast<uint32_t *>(g_lds + lay.bsad);
+    uint32_t *const bmv  = reinterpret_cast<uint32_t *>(g_lds + lay.bmv);
+    Shared sh = {st, lay.src64, lay.src32, lay.src16, lay.win, cshift};
 
     // XCD-aware work pull: queue q holds a contiguous band of b64 rows; start with this XCD's own band
     uint32_t xcc = 0;
@@ -947,10 +885,10 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
 
     for (;;) {
         // ---- fetch the next b64 job (fetching ahead was measured slower: it defeats the queues' load balancing) -------
-        if (tid == 0) st.job = fetch_job();
-        __syncthreads();
-        const int gjob = st.job;
-        if (gjob < 0) break; // every wave of the workgroup takes this exit together
+        int gjob = 0;
+        if (tid == 0) gjob = fetch_job();
+        gjob = __builtin_amdgcn_readfirstlane(gjob);
+        if (gjob < 0) break; // the exit condition every wave reaches: all queues empty
         PROF(0);
         // picture of this job (uniform): its parameter block is read with scalar loads
         int pic = 0;
@@ -965,6 +903,10 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         const int job      = gjob - (int)hdr.job_base[pic];
         const uint32_t bxi = (uint32_t)job % p.w64, byi = p.row0 + (uint32_t)job / p.w64;
         const uint32_t b   = bxi + byi * p.w64;
+        const int r0n      = d.num_of_ref_pic_to_search[0]; // row of (list, ref) in best_sad / best_mv: (list ? r0n : 0) + ref
+#define BEST_SAD(li, ri) (bsad + (((li) ? r0n : 0) + (ri)) * 85)
+#define BEST_MV(li, ri) (bmv + (((li) ? r0n : 0) + (ri)) * 85)
+        const int n_rows   = r0n + (nl > 1 ? d.num_of_ref_pic_to_search[1] : 0);
 
         // ---- block setup (me_process.c:183-214; motion_estimation.c:3090-3105, init_me_hme_data :3010-3071) ---
         if (tid == 0) {
@@ -977,7 +919,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             st.nreq = 0; st.nme = 0; st.nprobe = 0;
         }
         for (int i = tid; i < 3 * 2 * 4 * 2 * 2; i += kThreads) { (&st.hx[0][0][0][0][0])[i] = 0; (&st.hy[0][0][0][0][0])[i] = 0; (&st.hs[0][0][0][0][0])[i] = 0; }
-        for (int i = tid; i < 2 * 4 * 85; i += kThreads) { (&st.best_mv[0][0][0])[i] = 0; (&st.best_sad[0][0][0])[i] = SVT_HIP_MAX_SAD_VALUE; }
+        for (int i = tid; i < n_rows * 85; i += kThreads) { bmv[i] = 0; bsad[i] = SVT_HIP_MAX_SAD_VALUE; }
         if (tid < 8) {
             const int li = tid >> 2, ri = tid & 3;
             st.do_ref[li][ri] = 1; st.hme_sad64[li][ri] = 0xFFFFFFFFull; st.sr_divisor[li][ri] = 1; st.zz_sad[li][ri] = ~0u;
@@ -988,29 +930,29 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 st.performed_phme[li][ri][sri] = 0;
             }
         }
-        { // source views -> LDS.  The 64x64 is always loaded whole: the integer search reads all of it
-            const int ox = (int)(bxi * 64), oy = (int)(byi * 64);
-            for (int i = tid; i < 64 * 4; i += kThreads) {
+        { // source views -> LDS (every row, or the even rows only: cshift)
+            const int ox = (int)(bxi * 64), oy = (int)(byi * 64), rstep = 1 << cshift;
+            for (int i = tid; i < (64 >> cshift) * 4; i += kThreads) {
                 const int row = i >> 2, cc = i & 3;
-                uint4 v; memcpy(&v, plane_at(p.cur.lvl[2], ox + cc * 16, oy + row), 16);
-                *reinterpret_cast<uint4 *>(&sh.src64[row * kSrc64Pitch + cc * 16]) = v;
+                uint4 v; memcpy(&v, plane_at(p.cur.lvl[2], ox + cc * 16, oy + row * rstep), 16);
+                *reinterpret_cast<uint4 *>(&LDS(sh.src64)[row * kSrc64Pitch + cc * 16]) = v;
             }
-            for (int i = tid; i < 32 * 2; i += kThreads) {
+            for (int i = tid; i < (32 >> cshift) * 2; i += kThreads) {
                 const int row = i >> 1, cc = i & 1;
-                uint4 v; memcpy(&v, plane_at(p.cur.lvl[1], (ox >> 1) + cc * 16, (oy >> 1) + row), 16);
-                *reinterpret_cast<uint4 *>(&sh.src32[row * kSrc32Pitch + cc * 16]) = v;
+                uint4 v; memcpy(&v, plane_at(p.cur.lvl[1], (ox >> 1) + cc * 16, (oy >> 1) + row * rstep), 16);
+                *reinterpret_cast<uint4 *>(&LDS(sh.src32)[row * kSrc32Pitch + cc * 16]) = v;
             }
-            for (int i = tid; i < 16; i += kThreads) {
-                uint4 v; memcpy(&v, plane_at(p.cur.lvl[0], ox >> 2, (oy >> 2) + i), 16);
-                *reinterpret_cast<uint4 *>(&sh.src16[i * kSrc16Pitch]) = v;
+            for (int i = tid; i < (16 >> cshift); i += kThreads) {
+                uint4 v; memcpy(&v, plane_at(p.cur.lvl[0], ox >> 2, (oy >> 2) + i * rstep), 16);
+                *reinterpret_cast<uint4 *>(&LDS(sh.src16)[i * kSrc16Pitch]) = v;
             }
         }
-        __syncthreads();
+        wave_sync();
 
         PROF(1);
         // The stages below run as one loop around a SINGLE inlined copy of run_searches / run_me_searches (the kernel
-        // must stay small enough for the instruction cache shared by two CUs): each stage has a lane-0 "pre" part that
-        // pushes its searches and a lane-0 "post" part that folds the results into the block state.
+        // must stay small enough for the instruction cache shared by two CUs): each stage has a "pre" part that
+        // pushes its searches and a "post" part that folds the results into the block state.
         // ---- init_zz_sad (motion_estimation.c:2382-2437) ------------------------------------------------
         auto zz_pre = [&]() {
             if (tid == 0) {
@@ -1186,7 +1128,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     st.hx[0][li][ri][w][h] = (int16_t)((int16_t)(x + st.hx[0][li][ri][w][h]) * 4);
                     st.hy[0][li][ri][w][h] = (int16_t)((int16_t)(y + st.hy[0][li][ri][w][h]) * 4);
                 }
-                // the four regions of a reference are in LDS now (one wave: the stores above precede the loads below)
+                wave_sync(); // the four regions of a reference are in LDS now
                 if (k0 && h == 0 && w == 0 && c.prehme_enable) {
                     // get_worst_quadrant (:1872-1901): the last compare does not raise the max
                     int ww = 0, wh = 0; uint32_t mx = 0;
@@ -1374,7 +1316,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                             }
                             if (c.enable_me_sr_adjustment == 2) {
                                 if ((accurate && best_hme_sad < 24 * 24) || (d.is_ref && st.hme_sad64[li][ri] < 24 * 24)) sa_h = (int16_t)(sa_h / 2);
-                                if ((li || ri) && st.best_sad[0][0][0] < 5000 && sa_h == h0 && sa_w == w0) { sa_h = (int16_t)(sa_h >> 1); sa_w = (int16_t)(sa_w >> 1); }
+                                if ((li || ri) && BEST_SAD(0, 0)[0] < 5000 && sa_h == h0 && sa_w == w0) { sa_h = (int16_t)(sa_h >> 1); sa_w = (int16_t)(sa_w >> 1); }
                             }
                         }
                         MeReq &m = st.me[st.nme++];
@@ -1397,8 +1339,8 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     int16_t sa_w = m.sa_w, sa_h = m.sa_h;
                     const int cx = m.ox, cy = m.oy;
                     if (m.probe) { // :1391-1439 -- only one point was searched: 64x64 SAD == sum of the 8x8 SADs
-                        const uint32_t mean = st.best_sad[m.li][m.ri][0] / 64;
-                        const int32_t  dd   = (int32_t)st.best_sad[m.li][m.ri][21 + tid] - (int32_t)mean;
+                        const uint32_t mean = BEST_SAD(m.li, m.ri)[0] / 64;
+                        const int32_t  dd   = (int32_t)BEST_SAD(m.li, m.ri)[21 + tid] - (int32_t)mean;
                         const uint32_t var  = wave_sum((uint32_t)(dd * dd)) / 64;
                         if (var > c.me_sr_mult2_th) { sa_w = (int16_t)((imax(1, sa_w * 3 / 2) + 7) & ~7); sa_h = (int16_t)imax(1, sa_h * 3 / 2); }
                         if (var < c.me_sr_div4_th) { sa_w = (int16_t)((imax(1, sa_w >> 2) + 7) & ~7); sa_h = (int16_t)imax(3, imax(1, sa_h >> 2)); }
@@ -1414,12 +1356,15 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         };
 
         enum { kZz, kPrehme, kL0, kL1, kL2, kC00, kProbe, kMain, kEnd };
+#ifdef SVT_ME_ABLATE // diagnostic builds (instruction counting; results are wrong): 1 = no stages, 2 = stop behind HME level 2, 3 = no outputs
+        if (SVT_ME_ABLATE == 1) continue;
+#endif
         const int n_prehme = c.prehme_l1_early_exit ? nl : 1, n_l0 = l0_dep ? 2 : 1, n_group = me_dep ? 2 : 1;
         int step = kZz, bi = 0; // uniform: derived from launch parameters only
         PROF(2);
         while (step != kEnd) {
             bool run = true;
-            if (tid < 64) CTRL_PRIO(SVT_ME_CTRL_PRIO);
+            CTRL_PRIO(SVT_ME_CTRL_PRIO); // the stretches between the searches are on the block's critical path: ask for issue priority
             switch (step) {
             case kZz: run = c.me_early_exit_th || c.me_safe_limit_zz_th; if (run) zz_pre(); break;
             case kPrehme: run = c.prehme_enable; if (run) prehme_pre(bi); break;
@@ -1430,12 +1375,14 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             case kProbe: probe_pre(bi); break;
             default: main_pre(); break;
             }
+#ifdef SVT_ME_ABLATE
+            if (SVT_ME_ABLATE == 2 && step == kC00) break;
+            if (SVT_ME_ABLATE == 4 && run && step < kProbe) { step = step == kPrehme ? kL0 : step + 1; bi = 0; continue; } // no HME searches, no post
+            if (SVT_ME_ABLATE == 5 && run && step < kProbe) st.nreq = 0;
+#endif
             if (run) {
-                // wave 0 has just pushed the stage's searches: it plans their first round right away (same wave: its LDS writes
-                // are in order), so that one barrier publishes requests and plan together
-                if (step < kProbe && tid < 64 && st.nreq) plan_round(st, true);
-                if (tid < 64) CTRL_PRIO(0);
-                __syncthreads();
+                CTRL_PRIO(0);
+                wave_sync();
                 PROF(step == kMain ? 20 : 6 + step);
                 if (step == kC00 && bi == 0 && st.tf_exit) { step = kEnd; continue; } // uniform: LDS value read after the barrier
                 if (step < kProbe) {
@@ -1444,11 +1391,11 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     const bool   probe = step == kProbe;
                     const MeReq *list  = probe ? st.me_probe : st.me;
                     const int    count = probe ? st.nprobe : st.nme;
-                    run_me_searches(sh, p, list, count);
+                    run_me_searches(sh, p, list, count, bsad, bmv, r0n);
                 }
                 PROF(4);
             }
-            if (tid < 64) CTRL_PRIO(SVT_ME_CTRL_PRIO);
+            CTRL_PRIO(SVT_ME_CTRL_PRIO);
             switch (step) { // fold the results in, pick the next stage
             case kZz: if (run) zz_post(); step = kPrehme; break;
             case kPrehme:
@@ -1470,21 +1417,24 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 if (bi + 1 < n_group) { bi++; step = kC00; } else step = kEnd;
                 break;
             }
-            if (tid < 64) CTRL_PRIO(0);
-            if (run && step != kProbe && step != kMain) __syncthreads(); // the probe / final-window plans read what lane 0 itself wrote
+            CTRL_PRIO(0);
+            wave_sync();
             PROF(5);
         }
 
 
+#ifdef SVT_ME_ABLATE
+        if (SVT_ME_ABLATE == 2 || SVT_ME_ABLATE == 3) continue;
+#endif
         // ---- me_prune_ref (motion_estimation.c:1522-1565) ----------------------------------------------------
         if (c.enable_hme_flag && c.enable_me_hme_ref_pruning && !mctf) {
-            for (int r = tid >> 6; r < 8; r += kWaves) { // one wave per reference: sum of its 64 8x8 SADs
+            for (int r = 0; r < 8; r++) { // per reference: sum of its 64 8x8 SADs
                 const int li = r >> 2, ri = r & 3;
                 if (li >= nl || ri >= d.num_of_ref_pic_to_search[li]) continue;
-                const u64 t = st.do_ref[li][ri] ? (u64)wave_sum(st.best_sad[li][ri][21 + (tid & 63)]) : (u64)SVT_HIP_MAX_SAD_VALUE * 64;
+                const u64 t = st.do_ref[li][ri] ? (u64)wave_sum(BEST_SAD(li, ri)[21 + (tid & 63)]) : (u64)SVT_HIP_MAX_SAD_VALUE * 64;
                 if ((tid & 63) == 0) st.hme_sad64[li][ri] = t;
             }
-            __syncthreads();
+            wave_sync();
             if (tid == 0) {
                 const uint16_t th = c.prune_ref_if_me_sad_dev_bigger_than_th;
                 if (th != 0xFFFF) {
@@ -1494,7 +1444,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                         if ((st.hme_sad64[li][ri] - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
 
         PROF(13);
@@ -1513,13 +1463,13 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             };
             // The reference writes these arrays only partially (malloc'ed): every row starts from zero.  The block's rows
             // are assembled in LDS (the window arena is idle here) and leave as coalesced stores.
-            uint32_t *l_mv    = reinterpret_cast<uint32_t *>(sh.win);
-            uint8_t  *l_cand  = sh.win + 4 * n_pu * d.max_refs;
+            uint32_t *l_mv    = reinterpret_cast<uint32_t *>(LDS(sh.win));
+            uint8_t  *l_cand  = LDS(sh.win) + 4 * n_pu * d.max_refs;
             uint8_t  *l_total = l_cand + n_pu * d.max_cand;
             const int stage_dwords = (int)(4 * n_pu * d.max_refs + n_pu * d.max_cand + n_pu + 3) >> 2;
             static_assert(kWinBytes >= 85 * (4 * SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS + 32 + 1), "the result rows of one block fit the arena");
-            for (int i = tid; i < stage_dwords; i += kThreads) reinterpret_cast<uint32_t *>(sh.win)[i] = 0;
-            __syncthreads();
+            for (int i = tid; i < stage_dwords; i += kThreads) reinterpret_cast<uint32_t *>(LDS(sh.win))[i] = 0;
+            wave_sync();
             for (int n = tid; n < d.max_number_of_pus_per_sb; n += kThreads) {
                 const int use = use_pu(n);
                 const int row = (n > 4) ? c_z_to_raster[n] : n; // == pu below (c_z_to_raster is the identity on 0..4)
@@ -1528,9 +1478,9 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 uint32_t  nls = nl;
                 if (r0 == 1 && r1 == 0) { // construct_me_candidate_array_single_ref
                     const int pu   = c_z_to_raster[n];
-                    st.me_dist[pu] = st.best_sad[0][0][n];
+                    st.me_dist[pu] = BEST_SAD(0, 0)[n];
                     if (use) l_total[pu] = 1;
-                    if (st.do_ref[0][0] && use) { put_cand(0, pack(0, 0, 0, 0, 0)); l_mv[pu * d.max_refs] = st.best_mv[0][0][n]; }
+                    if (st.do_ref[0][0] && use) { put_cand(0, pack(0, 0, 0, 0, 0)); l_mv[pu * d.max_refs] = BEST_MV(0, 0)[n]; }
                 } else if (r0 == 1 && r1 == 1) { // construct_me_candidate_array_mrp_off
                     const int     pu = c_z_to_raster[n];
                     const uint8_t d0 = st.do_ref[0][0], d1 = (nls == 1) ? 0 : st.do_ref[1][0];
@@ -1538,7 +1488,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     const uint32_t prune_th = (d0 && d1) ? (uint32_t)c.prune_me_candidates_th : 0;
                     uint8_t  blk[2] = {d0, d1};
                     uint8_t  off = 0;
-                    const uint32_t s0 = st.best_sad[0][0][n], s1 = st.best_sad[1][0][n];
+                    const uint32_t s0 = BEST_SAD(0, 0)[n], s1 = BEST_SAD(1, 0)[n];
                     const uint32_t best = (d0 && d1) ? (s0 < s1 ? s0 : s1) : (d0 ? s0 : s1);
                     st.me_dist[pu] = best;
                     if (use) l_total[pu] = 1;
@@ -1547,16 +1497,16 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     for (uint32_t li = 0; li < nls && (use || off == 0); li++) {
                         if (!blk[li]) continue;
                         if (prune_th > 0) {
-                            const uint32_t dev = (st.best_sad[li][0][n] - best) * 100;
+                            const uint32_t dev = (BEST_SAD(li, 0)[n] - best) * 100;
                             if (dev > best * prune_th) { blk[li] = 0; continue; }
                         }
                         if (min_list != -1 && min_list != (int)li) {
-                            if (use) l_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
+                            if (use) l_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = BEST_MV(li, 0)[n];
                             continue;
                         }
                         if (use) {
                             put_cand(off, pack(li, 0, 0, li == 0 ? li : 24, li == 1 ? li : 24));
-                            l_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = st.best_mv[li][0][n];
+                            l_mv[pu * d.max_refs + (li ? d.max_l0 : 0)] = BEST_MV(li, 0)[n];
                         }
                         off++;
                     }
@@ -1570,19 +1520,19 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     for (uint32_t li = 0; li < nls; li++)
                         for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
                             blk[li][ri] = st.do_ref[li][ri];
-                            if (blk[li][ri]) best = st.best_sad[li][ri][n] < best ? st.best_sad[li][ri][n] : best;
+                            if (blk[li][ri]) best = BEST_SAD(li, ri)[n] < best ? BEST_SAD(li, ri)[n] : best;
                         }
                     st.me_dist[pu] = best;
                     for (uint32_t li = 0; li < nls && (use || off == 0); li++)
                         for (int ri = 0; ri < d.num_of_ref_pic_to_search[li] && (use || off == 0); ri++) {
                             if (!blk[li][ri]) continue;
                             if (prune_th > 0) {
-                                const uint32_t dev = (st.best_sad[li][ri][n] - best) * 100;
+                                const uint32_t dev = (BEST_SAD(li, ri)[n] - best) * 100;
                                 if (dev > best * prune_th) { blk[li][ri] = 0; continue; }
                             }
                             if (use) {
                                 put_cand(off, pack(li, ri, ri, li == 0 ? li : 24, li == 1 ? li : 24));
-                                l_mv[pu * d.max_refs + (li ? d.max_l0 : 0) + ri] = st.best_mv[li][ri][n];
+                                l_mv[pu * d.max_refs + (li ? d.max_l0 : 0) + ri] = BEST_MV(li, ri)[n];
                             }
                             off++;
                         }
@@ -1602,7 +1552,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 }
                 if (row < 88) st.cand0[row] = first;
             }
-            __syncthreads();
+            wave_sync();
             for (int i = tid; i < (int)(n_pu * d.max_refs); i += kThreads) o_mv[i] = l_mv[i];
             for (int i = tid; i < (int)(n_pu * d.max_cand); i += kThreads) o_cand[i] = l_cand[i];
             for (int i = tid; i < (int)n_pu; i += kThreads) o_total[i] = l_total[i];
@@ -1639,7 +1589,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                         int th;
                         if (low) { const int dist = (uint16_t)iabs((int)(int16_t)((a > bb ? a : bb) - (a < bb ? a : bb))); th = d.gm_use_distance_based_active_th ? imax(dist >> 1, 4) : 4; }
                         else     { const int dist = (uint16_t)iabs((int)(int16_t)(a - bb)); th = d.gm_use_distance_based_active_th ? imax(dist * 16, 32) : 32; }
-                        const uint32_t mv = st.best_mv[li][ri][idx];
+                        const uint32_t mv = BEST_MV(li, ri)[idx];
                         const int mx = (int)(int16_t)(mv & 0xFFFF) << 2, my = (int)(int16_t)(mv >> 16) << 2;
                         refk  = (int)(li * 4 + ri);
                         neg_x = mx < -th; pos_x = !neg_x && mx > th;
@@ -1676,8 +1626,8 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 for (int i = tid; i < 2 * 4 * 85; i += kThreads) {
                     const int li = i / (4 * 85), ri = (i / 85) & 3, nn = i % 85;
                     const bool ok = li < nl && ri < d.num_of_ref_pic_to_search[li] && st.do_ref[li][ri];
-                    if (p.res.sb_best_sad) p.res.sb_best_sad[(size_t)b * 680 + i] = ok ? st.best_sad[li][ri][nn] : SVT_HIP_MAX_SAD_VALUE;
-                    if (p.res.sb_best_mv) p.res.sb_best_mv[(size_t)b * 680 + i] = ok ? st.best_mv[li][ri][nn] : 0;
+                    if (p.res.sb_best_sad) p.res.sb_best_sad[(size_t)b * 680 + i] = ok ? BEST_SAD(li, ri)[nn] : SVT_HIP_MAX_SAD_VALUE;
+                    if (p.res.sb_best_mv) p.res.sb_best_mv[(size_t)b * 680 + i] = ok ? BEST_MV(li, ri)[nn] : 0;
                 }
             if (tid < 8) {
                 const int li = tid >> 2, ri = tid & 3;
@@ -1690,26 +1640,36 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         PROF(16);
     }
     PROF_FLUSH(hdr.queue_head + 16);
 }
 
-size_t svt_hip_me_kernel_lds_bytes(void) { return sizeof(Shared); }
+#undef BEST_SAD
+#undef BEST_MV
+
+size_t svt_hip_me_kernel_lds_bytes(void) { return lds_layout(SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS, 0).total; }
 
 #include "svt_hip_internal.h"
 
 // Host launcher: zero the lane's band queues, copy the header + parameter blocks to HBM through one block of the lane's
 // pinned ring (stream ordered: the previous launch on this lane has consumed the device block before the copy lands; the ring
-// lets SVT_HIP_PARAM_RING launches be enqueued ahead before the host has to wait) and enqueue the persistent workgroups on the
+// lets SVT_HIP_PARAM_RING launches be enqueued ahead before the host has to wait) and enqueue the persistent waves on the
 // lane's stream.  The caller holds the lane (lane 0: ctx->async_mu).
 int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures) {
     if (n_pictures == 0 || n_pictures > SVT_HIP_ME_MAX_PICTURES) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "%u pictures in one ME launch (1..%d)", n_pictures, SVT_HIP_ME_MAX_PICTURES);
     MeBatchHeader hdr;
     memset(&hdr, 0, sizeof(hdr));
     hdr.n_pictures = n_pictures;
-    for (uint32_t i = 0; i < n_pictures; i++) hdr.job_base[i + 1] = hdr.job_base[i] + n_jobs[i];
+    int all_sub = 1;
+    for (uint32_t i = 0; i < n_pictures; i++) {
+        hdr.job_base[i + 1] = hdr.job_base[i] + n_jobs[i];
+        const uint32_t rows = (uint32_t)params[i].desc.num_of_ref_pic_to_search[0] + (params[i].desc.num_of_list_to_search > 1 ? (uint32_t)params[i].desc.num_of_ref_pic_to_search[1] : 0u);
+        hdr.n_slot = rows > hdr.n_slot ? rows : hdr.n_slot; // rows of best_sad / best_mv a wave keeps in LDS
+        if (params[i].cfg.hme_search_method != 0 || params[i].cfg.me_search_method != 0) all_sub = 0;
+    }
+    hdr.cshift = (uint32_t)all_sub; // every search of the launch reads even source rows only: the source views keep just those
     for (uint32_t i = n_pictures; i < SVT_HIP_ME_MAX_PICTURES; i++) hdr.job_base[i + 1] = hdr.job_base[n_pictures];
     const uint32_t total = hdr.job_base[n_pictures];
     if (total == 0) return SVT_HIP_OK;
@@ -1717,13 +1677,17 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     for (int q = 0; q <= SVT_HIP_ME_QUEUES; q++) hdr.queue_begin[q] = (uint32_t)(((uint64_t)total * q) / SVT_HIP_ME_QUEUES);
     hdr.queue_head = lane->queue_head;
     SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->queue_head, 0, SVT_HIP_ME_QUEUES * sizeof(uint32_t), lane->stream));
-    const size_t lds = sizeof(Shared);
     if (!ctx->me_attr_set) { // per context = per device; racing first calls set the same value
         SVT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(svt_hip_me_b64_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)svt_hip_me_kernel_lds_bytes()));
         ctx->me_attr_set = true;
     }
-    uint32_t grid = (uint32_t)ctx->num_cus * (uint32_t)SVT_HIP_ME_WG_PER_CU; // persistent workgroups: what the launch bounds and the LDS footprint keep resident
+    // persistent waves: as many per CU as the LDS slices (the window arena + the launch's best_sad / best_mv rows) and the register
+    // budget of the launch bounds keep resident
+    const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift).total + 127) & ~(size_t)127;
+    uint32_t per_cu = (uint32_t)((160u * 1024u) / lds);
+    if (per_cu > 4u * SVT_HIP_ME_WAVES_PER_SIMD) per_cu = 4u * SVT_HIP_ME_WAVES_PER_SIMD;
+    uint32_t grid = (uint32_t)ctx->num_cus * per_cu;
     if (grid > total) grid = total;
     const int slot = lane->ring_next;
     lane->ring_next = (slot + 1) % SVT_HIP_PARAM_RING;
@@ -1733,7 +1697,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     memcpy(host + SVT_HIP_ME_HEADER_BYTES, params, sizeof(MeKernelParams) * n_pictures);
     SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * n_pictures, hipMemcpyHostToDevice, lane->stream));
     SVT_HIP_CHECK(ctx, hipEventRecord(lane->params_copied[slot], lane->stream));
-    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(SVT_HIP_ME_THREADS), lds, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
+    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(64), lds, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
                        reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES));
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
