@@ -24,6 +24,19 @@ extern "C" {
 
 int svt_hip_leaf_bind(SvtHipContext *ctx); /* NULL unbinds */
 
+/* Installer: what svt_aom_setup_rtcd_internal (Codec/aom_dsp_rtcd.c:188; called at Globals/enc_handle.c:1444-1445) does for one SIMD
+ * flavour.  A slot names one of the encoder's rtcd function pointers (the identifier in aom_dsp_rtcd.h / common_dsp_rtcd.h, e.g.
+ * "svt_sad_loop_kernel") and gives the ADDRESS of that pointer variable; svt_hip_install_rtcd stores this library's entry with the same
+ * prototype there (<name>_hip) and binds `ctx` for the pointer-level entries.  Names without an entry here are left untouched (the
+ * encoder keeps its own kernel) and counted in *n_skipped.  Run it after the encoder's own set-up and before init_fn_ptr()
+ * (Codec/av1me.c:31, enc_handle.c:1460: it copies pointer values).  svt_hip_rtcd_lookup returns the entry alone (NULL: none). */
+typedef struct SvtHipRtcdSlot {
+    const char *name;
+    void      **slot;
+} SvtHipRtcdSlot;
+int         svt_hip_install_rtcd(SvtHipContext *ctx, const SvtHipRtcdSlot *slots, uint32_t n_slots, uint32_t *n_skipped);
+const void *svt_hip_rtcd_lookup(const char *name);
+
 /* svt_sad_loop_kernel (aom_dsp_rtcd.h:779; C_DEFAULT/compute_sad_c.c:58-101) */
 void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
                              uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center,

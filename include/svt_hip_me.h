@@ -191,6 +191,10 @@ int  svt_hip_pa_picture_create(SvtHipContext *ctx, const SvtHipPlaneDesc *full, 
                                const SvtHipPlaneDesc *sixteenth, SvtHipPaPicture **pic);
 /* same, but `full_dev` points to device memory already laid out as `full` describes (no H2D copy) */
 int  svt_hip_pa_picture_create_dev(SvtHipContext *ctx, const SvtHipPlaneDesc *full_dev, SvtHipPaPicture **pic);
+/* Refill an existing picture (a pooled buffer, as the reference recycles its EbPaReferenceObject buffers) with a new full-resolution plane of
+ * the same geometry and rebuild the 1/4 and 1/16 planes on the device; enqueued on the context stream (asynchronous when `full` is page-locked
+ * host memory or, with full_on_device != 0, device memory). */
+int  svt_hip_pa_picture_update(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device);
 void svt_hip_pa_picture_destroy(SvtHipContext *ctx, SvtHipPaPicture *pic);
 /* copies level (0 = sixteenth, 1 = quarter, 2 = full) back into a host plane of identical geometry */
 int  svt_hip_pa_picture_download(SvtHipContext *ctx, const SvtHipPaPicture *pic, int level, uint8_t *dst,

@@ -26,9 +26,21 @@
  * ===================================================================================== */
 
 /* svt_fast_loop_nxm_sad_kernel / svt_nxm_sad_kernel_helper_c: C_DEFAULT/compute_sad_c.c:20-37,209 */
+/* Diagnostic: the number of |a - b| evaluations the SAD kernels made (every SAD of the path goes through orc_nxm_sad): the work measure
+ * bench.py relates to the packed-SAD issue rate of the GPU ("fraction of packed-SAD VALU peak").  Counted per thread, added to
+ * the global sum when the thread's orc_me_picture call returns. */
+static __thread uint64_t t_sad_ops;
+static uint64_t          g_sad_ops;
+uint64_t orc_sad_ops(int reset) {
+    const uint64_t v = __atomic_load_n(&g_sad_ops, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(&g_sad_ops, 0, __ATOMIC_RELAXED);
+    return v;
+}
+
 uint32_t orc_nxm_sad(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height,
                      uint32_t width) {
     uint32_t acc = 0;
+    t_sad_ops += (uint64_t)height * width;
     for (uint32_t r = 0; r < height; r++)
         for (uint32_t c = 0; c < width; c++) {
             int d = (int)src[r * src_stride + c] - (int)ref[r * ref_stride + c];
@@ -1020,6 +1032,7 @@ int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
     const uint32_t w64 = (desc->aligned_width + 63) / 64, h64 = (desc->aligned_height + 63) / 64;
     const uint32_t row0 = desc->b64_row_start, nrow = desc->b64_row_count ? desc->b64_row_count : h64 - row0;
     const uint32_t n_pu = svt_hip_me_n_pu(desc->enable_me_16x16, desc->enable_me_8x8);
+    t_sad_ops = 0;
     /* desc->aligned_* == ALIGN_POWER_OF_TWO(input width/height, 3) (motion_estimation.c:3093-3094, pcs.c:1496-1497) */
     const uint16_t aw = desc->aligned_width, ah = desc->aligned_height;
     for (uint32_t by = row0; by < row0 + nrow && by < h64; by++)
@@ -1119,6 +1132,7 @@ int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
                 }
         }
     free(s);
+    __atomic_fetch_add(&g_sad_ops, t_sad_ops, __ATOMIC_RELAXED);
     return SVT_HIP_OK;
 }
 

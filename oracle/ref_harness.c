@@ -36,6 +36,7 @@ static int g_simd = 0;
  * pointers this path calls: flags == 0 -> `_c`, otherwise the AVX2/SSE4.1/SSE2 picks of that table. */
 void ref_set_simd(int use_avx2) {
     g_simd = use_avx2;
+    if (use_avx2 == 2) return; /* 2: leave the pointers as an external installer set them (ref_rtcd_slot) */
 #ifdef REF_WITH_AVX2
     if (use_avx2) {
         svt_sad_loop_kernel                        = svt_sad_loop_kernel_avx2_intrin;
@@ -590,3 +591,13 @@ int ref_pyramid(const SvtHipPlaneDesc *full, const SvtHipPlaneDesc *quarter, con
 /* get_hvs_modulation_factor is not declared in a header every caller includes */
 double get_hvs_modulation_factor(double psy_rd, bool is_islice, uint8_t temporal_layer_index);
 double ref_hvs_modulation_factor(double psy_rd, int is_islice, uint8_t temporal_layer_index) { return get_hvs_modulation_factor(psy_rd, is_islice != 0, temporal_layer_index); }
+
+/* Address of one of the reference's rtcd function-pointer variables (the globals svt_aom_setup_rtcd_internal fills): lets a test install
+ * another backend's kernels into the reference exactly where its own SIMD kernels go.  NULL: not a pointer this harness knows. */
+void **ref_rtcd_slot(const char *name) {
+#define SLOT(n) if (!strcmp(name, #n)) return (void **)&n;
+    SLOT(svt_sad_loop_kernel) SLOT(svt_nxm_sad_kernel) SLOT(svt_ext_all_sad_calculation_8x8_16x16) SLOT(svt_ext_eight_sad_calculation_32x32_64x64)
+    SLOT(svt_ext_sad_calculation_8x8_16x16) SLOT(svt_ext_sad_calculation_32x32_64x64) SLOT(svt_initialize_buffer_32bits)
+#undef SLOT
+    return NULL;
+}

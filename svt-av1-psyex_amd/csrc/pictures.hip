@@ -171,6 +171,30 @@ int svt_hip_pa_picture_create_dev(SvtHipContext *ctx, const SvtHipPlaneDesc *ful
     return create_common(ctx, full_dev, nullptr, nullptr, true, pic);
 }
 
+// A picture buffer taken from a pool and filled with the next input picture (the reference recycles its EbPaReferenceObject buffers the
+// same way, Codec/reference_object.c): the full plane is copied in again (from page-locked host memory the copy is asynchronous), the
+// 1/4 and 1/16 planes are rebuilt on the device.  Enqueued on the context stream.
+int svt_hip_pa_picture_update(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device) {
+    if (!ctx || !pic) return SVT_HIP_ERR_BAD_PARAM;
+    int rc = check_plane(ctx, full, 64, "full");
+    if (rc) return rc;
+    DevPlane &f = pic->pyr.lvl[2];
+    if (full->width != f.width || full->height != f.height || full->org_x != f.org_x || full->org_y != f.org_y)
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "update: plane %ux%u pad %u,%u does not match the picture's %dx%d pad %d,%d", full->width, full->height,
+                            full->org_x, full->org_y, f.width, f.height, f.org_x, f.org_y);
+    hipSetDevice(ctx->device);
+    if ((rc = upload_plane(ctx, full, &f, full_on_device != 0))) return rc;
+    for (int level = 1; level >= 0; level--) {
+        const DevPlane &src = pic->pyr.lvl[level + 1], &dst = pic->pyr.lvl[level];
+        const int pw = dst.width + 2 * dst.org_x, ph = dst.height + 2 * dst.org_y;
+        hipLaunchKernelGGL(downsample2x_pad_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, ctx->stream, src, dst);
+    }
+    SVT_HIP_CHECK(ctx, hipGetLastError());
+    SVT_HIP_CHECK(ctx, hipEventRecord(pic->ready, ctx->stream));
+    pic->ready_stream = ctx->stream;
+    return SVT_HIP_OK;
+}
+
 void svt_hip_pa_picture_destroy(SvtHipContext *ctx, SvtHipPaPicture *pic) {
     if (!pic) return;
     if (ctx) {

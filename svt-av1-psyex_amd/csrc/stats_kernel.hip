@@ -17,6 +17,7 @@
 // (which is why this is butterfly code on the VALU and not an MFMA contraction: the shifts between the 8 / 16 / 32
 // stages are not linear, and 9-bit residuals do not fit the 8-bit integer MFMA operands).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -462,6 +463,47 @@ int svt_hip_leaf_bind(SvtHipContext *ctx) {
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     g_leaf_ctx = ctx;
     return SVT_HIP_OK;
+}
+
+// The `_hip` entry that takes the place of the reference's function pointer `name`: the exported symbol <name>_hip of this library
+// (the pointer-level entries carry the reference's pointer names), or the one the short alias table names where the reference's
+// pointer and its `_c` body are called differently.
+const void *svt_hip_rtcd_lookup(const char *name) {
+    static const struct { const char *pointer, *symbol; } alias[] = {
+        {"svt_nxm_sad_kernel", "svt_nxm_sad_kernel_helper_hip"},          // aom_dsp_rtcd.h:125 -> svt_nxm_sad_kernel_helper_c
+        {"svt_aom_quantize_b", "svt_aom_quantize_b_hip"},                 // -> svt_aom_quantize_b_c_ii
+        {"svt_aom_sad_16b_kernel", "svt_aom_sad_16b_kernel_hip"},
+    };
+    if (!name || !*name || strlen(name) > 200) return nullptr;
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void *>(&svt_hip_leaf_bind), &info) || !info.dli_fname) return nullptr;
+    void *self = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+    if (!self) return nullptr;
+    char sym[256];
+    snprintf(sym, sizeof(sym), "%s_hip", name);
+    for (const auto &a : alias)
+        if (!strcmp(a.pointer, name)) snprintf(sym, sizeof(sym), "%s", a.symbol);
+    const void *fn = dlsym(self, sym);
+    dlclose(self);
+    return fn;
+}
+
+// What svt_aom_setup_rtcd_internal (Codec/aom_dsp_rtcd.c:188, called at Globals/enc_handle.c:1444-1445) does for a SIMD flavour: assign
+// this backend's entries into the encoder's function pointers.  `slots[i].slot` is the ADDRESS of the encoder's pointer variable
+// `slots[i].name`.  Names this library has no entry for are left as they are (the encoder keeps its own kernel there) and counted in
+// *n_skipped.  Binds `ctx` for the pointer-level entries (they have no context argument).  Call it before init_fn_ptr()
+// (Codec/av1me.c:31, enc_handle.c:1460), which copies pointer VALUES into svt_aom_mefn_ptr[].
+int svt_hip_install_rtcd(SvtHipContext *ctx, const SvtHipRtcdSlot *slots, uint32_t n_slots, uint32_t *n_skipped) {
+    if (!ctx || (!slots && n_slots)) return SVT_HIP_ERR_BAD_PARAM;
+    uint32_t skipped = 0;
+    for (uint32_t i = 0; i < n_slots; i++) {
+        if (!slots[i].slot) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "rtcd slot %u (%s): null address", i, slots[i].name ? slots[i].name : "?");
+        const void *fn = svt_hip_rtcd_lookup(slots[i].name);
+        if (!fn) { skipped++; continue; }
+        *slots[i].slot = const_cast<void *>(fn);
+    }
+    if (n_skipped) *n_skipped = skipped;
+    return svt_hip_leaf_bind(ctx);
 }
 
 } // extern "C"

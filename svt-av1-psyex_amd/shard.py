@@ -36,46 +36,57 @@ def rows_max(h64, world):
 
 
 class BandLayout:
-    """Byte layout of one rank's compact result buffer for `n_pictures` pictures: [picture][field][rows_max * w64][elems]."""
+    """Byte layout of one rank's compact result buffer for `n_pictures` pictures: [picture][field][the rank's rows of that picture * w64][elems]
+    -- live rows only.  Ranks may own different numbers of rows (rank_bytes); with the rotation the totals are equal whenever
+    n_pictures * (h64 % world) is a multiple of world (16 pictures of 34 rows on 8, 4 or 2 ranks).  `nbytes` is the size every rank
+    allocates (the largest rank's bytes), `offsets()` / `rank_bytes` are what an all-gather-v needs."""
 
     def __init__(self, w64, h64, world, n_pu, max_refs, max_cand, n_pictures=1):
         self.w64, self.h64, self.world, self.n_pictures = w64, h64, world, n_pictures
         self.fields = [(n, np.dtype(dt), c(n_pu, max_refs, max_cand)) for n, dt, c in abi.RESULT_FIELDS if n in GATHER_FIELDS]
-        self.nbb = rows_max(h64, world) * w64
         self.bytes_per_b64 = sum(dt.itemsize * c for _, dt, c in self.fields)
-        self.nbytes = n_pictures * self.nbb * self.bytes_per_b64
+        self.bands = [[band(h64, r, world, rotation(p, h64, world)) for p in range(n_pictures)] for r in range(world)]
+        self.rank_rows = [sum(r1 - r0 for r0, r1 in self.bands[r]) for r in range(world)]
+        self.rank_bytes = [rows * w64 * self.bytes_per_b64 for rows in self.rank_rows]
+        self.nbytes = max(self.rank_bytes)
+        self.uniform = len(set(self.rank_bytes)) == 1  # a plain all-gather moves live bytes only
 
     def band(self, picture, rank):
-        """[row0, row1) of `rank` in the `picture`-th picture of the exchange."""
-        return band(self.h64, rank, self.world, rotation(picture, self.h64, self.world))
+        """[row0, row1) of `rank` in the `picture`-th picture of the exchange (may be empty when world > h64)."""
+        return self.bands[rank][picture]
 
-    def field_offsets(self, picture):
-        """name -> (byte offset of the field's first band row, bytes per b64)."""
-        off = picture * self.nbb * self.bytes_per_b64
+    def offsets(self):
+        """Byte offset of every rank's buffer in the gathered buffer: all-gather layout (rank r at r * nbytes)."""
+        return [r * self.nbytes for r in range(self.world)]
+
+    def field_offsets(self, picture, rank):
+        """name -> (byte offset of the field's first band row in `rank`'s buffer, bytes per b64)."""
+        off = sum(r1 - r0 for r0, r1 in self.bands[rank][:picture]) * self.w64 * self.bytes_per_b64
+        r0, r1 = self.bands[rank][picture]
+        nb = (r1 - r0) * self.w64
         out = {}
         for n, dt, c in self.fields:
             out[n] = (off, dt.itemsize * c)
-            off += self.nbb * dt.itemsize * c
+            off += nb * dt.itemsize * c
         return out
 
     def results_struct(self, base_ptr, picture, rank):
         """abi.MeResults whose pointers are biased so that absolute b64 indices of `rank`'s band land in its compact buffer."""
         first = self.band(picture, rank)[0] * self.w64
         res = abi.MeResults()
-        for n, (off, per) in self.field_offsets(picture).items():
+        for n, (off, per) in self.field_offsets(picture, rank).items():
             setattr(res, n, base_ptr + off - first * per)
         return res
 
     def unpack(self, gathered, picture):
         """gathered: uint8 array [world, nbytes] (all ranks' compact buffers).  Returns name -> full-picture array [n_b64, elems]."""
         gathered = np.asarray(gathered).reshape(self.world, self.nbytes)
-        out = {}
-        for n, dt, c in self.fields:
-            off, per = self.field_offsets(picture)[n]
-            full = np.zeros((self.w64 * self.h64, c), dt)
-            for r in range(self.world):
-                r0, r1 = self.band(picture, r)
-                nb = (r1 - r0) * self.w64
-                full[r0 * self.w64:r1 * self.w64] = gathered[r, off:off + nb * per].view(dt).reshape(nb, c)
-            out[n] = full
+        out = {n: np.zeros((self.w64 * self.h64, c), dt) for n, dt, c in self.fields}
+        for r in range(self.world):
+            r0, r1 = self.band(picture, r)
+            nb = (r1 - r0) * self.w64
+            fo = self.field_offsets(picture, r)
+            for n, dt, c in self.fields:
+                off, per = fo[n]
+                out[n][r0 * self.w64:r1 * self.w64] = gathered[r, off:off + nb * per].view(dt).reshape(nb, c)
         return out
