@@ -5,6 +5,8 @@ the compiled libraries (``svt_hip_sizeof`` / ``orc_sizeof``).
 """
 import ctypes as C
 
+import numpy as np
+
 MAX_LISTS = 2
 MAX_REFS = 4
 SQUARE_PU_COUNT = 85
@@ -187,3 +189,24 @@ FACADE_OUT_FIELDS = [("facade_dist", "<u8")]
 VAR10_OUT_FIELDS = [("variance10", "<u4"), ("var_sse10", "<u4")]  # 10-bit planes only
 VARIANCE_SIZES = [(4, 4), (4, 8), (4, 16), (8, 4), (8, 8), (8, 16), (8, 32), (16, 4), (16, 8), (16, 16), (16, 32), (16, 64), (32, 8), (32, 16),
                   (32, 32), (32, 64), (64, 16), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128)]
+
+
+# ---- include/svt_hip_pme.h ----
+class Mv(C.Structure):
+    _fields_ = [("row", C.c_int16), ("col", C.c_int16)]
+
+
+class MvCostParam(C.Structure):  # MV_COST_PARAMS, Codec/mcomp.h:37-48
+    _fields_ = [("ref_mv", C.POINTER(Mv)), ("full_ref_mv", Mv), ("mv_cost_type", C.c_int), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2),
+                ("error_per_bit", C.c_int), ("early_exit_th", C.c_int), ("sad_per_bit", C.c_int)]
+
+
+PME_JOB_DTYPE = np.dtype([("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("start_x", "<i2"), ("start_y", "<i2"), ("sa_w", "<i2"),
+                          ("sa_h", "<i2"), ("step", "<i2"), ("mvx", "<i2"), ("mvy", "<i2"), ("ref_mv", "<i2", (2,)), ("best_cost", "<u4"), ("best_mvx", "<i2"),
+                          ("best_mvy", "<i2")], align=True)
+
+
+class PmeBatchDesc(C.Structure):
+    _fields_ = [("n_jobs", C.c_uint32), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("src", C.c_void_p), ("ref", C.c_void_p), ("jobs", C.c_void_p),
+                ("mv_cost_type", C.c_int32), ("error_per_bit", C.c_int32), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2), ("best_cost", C.c_void_p),
+                ("best_mv", C.c_void_p)]

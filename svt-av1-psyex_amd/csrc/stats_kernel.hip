@@ -465,6 +465,17 @@ int svt_hip_leaf_bind(SvtHipContext *ctx) {
     return SVT_HIP_OK;
 }
 
+// for the pointer-level entries that live in other files (pme_kernel.hip)
+int svt_hip_leaf_context(SvtHipContext **out) {
+    std::lock_guard<std::mutex> lock(g_leaf_mutex);
+    if (!g_leaf_ctx) {
+        fprintf(stderr, "libsvthip: a _hip leaf kernel was called before svt_hip_leaf_bind(); there is no CPU fallback\n");
+        abort();
+    }
+    *out = g_leaf_ctx;
+    return SVT_HIP_OK;
+}
+
 // The `_hip` entry that takes the place of the reference's function pointer `name`: the exported symbol <name>_hip of this library
 // (the pointer-level entries carry the reference's pointer names), or the one the short alias table names where the reference's
 // pointer and its `_c` body are called differently.
