@@ -81,6 +81,18 @@ struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
     int16_t        pad1;
 };
 
+// One tile of a round as the store / evaluation passes need it (the planning pass has the full geometry in scalar registers)
+constexpr int kRoundTiles = 8;
+struct __attribute__((aligned(8))) TileEnt {
+    int16_t  x0, y0, w, h;   // sub-area of the request's search area
+    uint16_t pitch, lds_vec; // LDS row pitch; first 16-byte vector of the tile in the arena
+    uint16_t nvec;           // vectors of the window
+    uint8_t  slot0, req;     // first register slot of its vectors while they are in flight; request index
+    uint8_t  bw, bh, rs, flags; // flags: level | skip_even << 2 | narrow << 3 | last << 4
+    uint32_t pad;
+};
+static_assert(sizeof(TileEnt) == 24, "TileEnt is read as three 8-byte words");
+
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
     const uint8_t *pix0; // reference sample co-located with the block's top-left, MV (0,0)
     uint32_t       stride;
@@ -121,6 +133,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
         struct { MeReq me[8], me_probe[8]; };
     };
     u64      req_key[kMaxReq];
+    TileEnt  tile[2][kRoundTiles];  // the tiles of the round in the arena and of the round on its way (see run_searches)
     uint32_t sadbuf[kNarrowMaxPos]; // per-position sums of a narrow (row-split) search
     int      nme, nprobe;
     uint32_t me_dist[85];
@@ -435,37 +448,40 @@ __device__ __forceinline__ TileGeo next_tile(const St &st, int nreq, TileCursor 
     return t;
 }
 
-// the tile's window, global -> registers: lane l owns vectors l, l + 64, ... of the flattened (row, vector) space.  The rows start at
+// the tile's window, global -> registers: lane l owns vectors l, l + 64, ... of the tile's flattened (row, vector) space; they go into the
+// register slots S0 .. S0 + NS - 1 (compile-time numbers: a runtime slot index would send the array to scratch memory).  The rows start at
 // an arbitrary byte: unaligned 16-byte loads (position x0 lands on LDS byte 0 of its row, so a tile has no dead leading positions)
 typedef uint32_t V4U __attribute__((ext_vector_type(4), aligned(1)));
 typedef const __attribute__((address_space(1))) V4U GV4U;
+constexpr int kSmallVec = 128; // a tile of at most this many vectors takes two slots: four such tiles share a round
+template <int S0, int NS>
 __device__ __forceinline__ void tile_load(const TileGeo &t, V4 (&v)[kVecPerLane]) {
-    const int lane = threadIdx.x, vpr = t.pitch >> 4;
+    const int lane = threadIdx.x, vpr = t.pitch >> 4, last_row = (t.nvec - 1) / vpr;
     int row = (int)div_by_rcp((uint32_t)lane, rcp_of((uint32_t)vpr)), c = lane - row * vpr; // vector `lane`; later passes advance by (kd, km)
 #pragma unroll
-    for (int j = 0; j < kVecPerLane; j++)
+    for (int j = 0; j < NS; j++)
         if (j * 64 < t.nvec) { // uniform
             // lanes past the end re-load the last row's vector c (harmless; the load stays unconditional)
-            const int rr = imin(row, (t.nvec - 1) / vpr);
-            const V4U q = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(t.g0 + (long long)rr * t.stride + c * 16));
-            v[j] = V4{q.x, q.y, q.z, q.w};
+            const int rr = imin(row, last_row);
+            v[S0 + j] = __builtin_bit_cast(V4, *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(t.g0 + (long long)rr * t.stride + c * 16)));
             row += t.kd; c += t.km;
             if (c >= vpr) { c -= vpr; row++; }
         }
 }
-__device__ __forceinline__ void tile_store(const Shared &sh, const TileGeo &t, const V4 (&v)[kVecPerLane]) {
+template <int S0, int NS>
+__device__ __forceinline__ void tile_store(const Shared &sh, int nvec, int lds_vec, const V4 (&v)[kVecPerLane]) {
     const int lane = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < kVecPerLane; j++)
-        if (j * 64 < t.nvec && lane + j * 64 < t.nvec) *reinterpret_cast<V4 *>(&LDS(sh.win)[(lane + j * 64) * 16]) = v[j];
+    for (int j = 0; j < NS; j++)
+        if (j * 64 < nvec && lane + j * 64 < nvec) *reinterpret_cast<V4 *>(&LDS(sh.win)[(lds_vec + lane + j * 64) * 16]) = v[S0 + j];
 }
 
 // every position of the tile in the arena; returns the tile's best key (sad << 32 | y << 16 | x), ~0 when no position was evaluated
-__device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t) {
+__device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t, int lds_off) {
     St            &st   = sh.st;
     const int      lane = threadIdx.x;
     const uint8_t *src  = src_view(sh, t.level);
-    const uint8_t *win  = LDS(sh.win);
+    const uint8_t *win  = LDS(sh.win) + lds_off;
     const int      sp   = (t.level == 2) ? kSrc64Pitch : (t.level == 1 ? kSrc32Pitch : kSrc16Pitch);
     const int      srs  = t.rs >> sh.cshift; // source row step: the views keep every (1 << cshift)-th row
     uint32_t bsad_ = 0xFFFFFFFFu, bpos_ = 0xFFFFFFFFu;
@@ -522,33 +538,94 @@ __device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t) {
     return wave_min_key(bsad_, bpos_);
 }
 
+// Plans the next round and sends its windows on their way into the register slots: either ONE tile of any size that fits the arena (all
+// slots), or up to four small tiles (at most kSmallVec vectors each: slots 2i, 2i + 1) while they fit the arena together.  The tiles'
+// entries go to st.tile[par][] for the later passes.  Returns the number of tiles.
+__device__ __forceinline__ void write_entry(St &st, int par, int i, const TileGeo &t, int lds_vec, int slot0) {
+    if (threadIdx.x == 0) {
+        TileEnt e;
+        e.x0 = (int16_t)t.x0; e.y0 = (int16_t)t.y0; e.w = (int16_t)t.w; e.h = (int16_t)t.h;
+        e.pitch = (uint16_t)t.pitch; e.lds_vec = (uint16_t)lds_vec; e.nvec = (uint16_t)t.nvec; e.slot0 = (uint8_t)slot0; e.req = (uint8_t)t.req;
+        e.bw = (uint8_t)t.bw; e.bh = (uint8_t)t.bh; e.rs = (uint8_t)t.rs;
+        e.flags = (uint8_t)(t.level | (t.skip_even << 2) | (t.narrow << 3) | (t.last << 4));
+        e.pad = 0;
+        st.tile[par][i] = e;
+    }
+}
+__device__ __forceinline__ int plan_and_load(St &st, int nreq, TileCursor &cur, V4 (&v)[kVecPerLane], int par) {
+    TileGeo t = next_tile(st, nreq, cur);
+    if (t.req < 0) return 0;
+    if (t.nvec > kSmallVec) {
+        tile_load<0, kVecPerLane>(t, v);
+        write_entry(st, par, 0, t, 0, 0);
+        return 1;
+    }
+    int nt = 0, vecs = 0;
+#define SVT_SMALL_TILE(I)                                                                                              \
+    tile_load<(2 * I < kVecPerLane ? 2 * I : 0), 2>(t, v);                                                             \
+    write_entry(st, par, I, t, vecs, 2 * I);                                                                           \
+    vecs += t.nvec; nt = I + 1;
+#define SVT_NEXT_SMALL()                                                                                               \
+    { const TileCursor save = cur; t = next_tile(st, nreq, cur);                                                       \
+      if (t.req < 0) return nt;                                                                                        \
+      if (t.nvec > kSmallVec || vecs + t.nvec > kWinBytes / 16) { cur = save; return nt; } }
+    SVT_SMALL_TILE(0) SVT_NEXT_SMALL() SVT_SMALL_TILE(1) SVT_NEXT_SMALL() SVT_SMALL_TILE(2) SVT_NEXT_SMALL() SVT_SMALL_TILE(3)
+#undef SVT_SMALL_TILE
+#undef SVT_NEXT_SMALL
+    return nt;
+}
+static_assert(kVecPerLane >= 8 && kRoundTiles >= 4, "four small tiles of two slots each");
+
 // The wave runs st.req[0 .. nreq) (nreq >= 1) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x), or
-// (0xffffff << 32 | 0xffffffff) when no position was evaluated.  While a tile is evaluated out of the arena, the next tile's
-// window is already on its way into registers.
+// (0xffffff << 32 | 0xffffffff) when no position was evaluated.  The searches go through the arena in ROUNDS of as many windows as it
+// holds (the eight level-0 windows of a short-distance picture are one round, a level-2 window is a round of its own); while a round is
+// evaluated out of the arena, the next round's windows are already on their way into registers.
 __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
     St        &st   = sh.st;
     const int  nreq = (int)uni((uint32_t)st.nreq);
     TileCursor cur  = {0, 0, 0, 0, 0};
     V4         v[kVecPerLane];
-    TileGeo    t = next_tile(st, nreq, cur);
-    tile_load(t, v);
+    int        par = 0, nt = plan_and_load(st, nreq, cur, v, 0);
     u64 key = (0xffffffull << 32) | 0xffffffffull;
     PROF(17);
-    while (t.req >= 0) {
-        tile_store(sh, t, v);
+    while (nt) {
+        wave_sync(); // the round's entries
+        { // slots are compile-time: a single big tile sits in all of them, small tile i in slots 2i, 2i + 1
+            const int n0 = (int)uni(st.tile[par][0].nvec);
+            if (n0 > kSmallVec) tile_store<0, kVecPerLane>(sh, n0, 0, v);
+            else {
+                tile_store<0, 2>(sh, n0, 0, v);
+                if (nt > 1) tile_store<2, 2>(sh, (int)uni(st.tile[par][1].nvec), (int)uni(st.tile[par][1].lds_vec), v);
+                if (nt > 2) tile_store<4, 2>(sh, (int)uni(st.tile[par][2].nvec), (int)uni(st.tile[par][2].lds_vec), v);
+                if (nt > 3) tile_store<6, 2>(sh, (int)uni(st.tile[par][3].nvec), (int)uni(st.tile[par][3].lds_vec), v);
+            }
+        }
         wave_sync();
         PROF(18);
-        const TileGeo nx = next_tile(st, nreq, cur);
-        if (nx.req >= 0) tile_load(nx, v);
-        const u64 k = tile_eval(sh, t);
-        key = k < key ? k : key;
-        if (t.last) {
-            if (threadIdx.x == 0) st.req_key[t.req] = key;
-            key = (0xffffffull << 32) | 0xffffffffull;
+        const int nn = plan_and_load(st, nreq, cur, v, par ^ 1);
+        for (int i = 0; i < nt; i++) {
+            const TileEnt &e = st.tile[par][i];
+            TileGeo t;
+            { // uniform entry -> scalar registers
+                const uint32_t a = uni((uint32_t)(uint16_t)e.x0 | ((uint32_t)(uint16_t)e.y0 << 16)), b = uni((uint32_t)(uint16_t)e.w | ((uint32_t)(uint16_t)e.h << 16));
+                const uint32_t c = uni((uint32_t)e.pitch | ((uint32_t)e.lds_vec << 16)), d = uni((uint32_t)e.req | ((uint32_t)e.bw << 8) | ((uint32_t)e.bh << 16) | ((uint32_t)e.rs << 24));
+                const uint32_t f = uni(e.flags);
+                t.x0 = (int16_t)(a & 0xFFFF); t.y0 = (int16_t)(a >> 16); t.w = (int16_t)(b & 0xFFFF); t.h = (int16_t)(b >> 16);
+                t.pitch = (int)(c & 0xFFFF); t.nvec = 0; t.kd = t.km = 0; t.g0 = nullptr; t.stride = 0;
+                t.req = (int)(d & 0xFF); t.bw = (int)((d >> 8) & 0xFF); t.bh = (int)((d >> 16) & 0xFF); t.rs = (int)(d >> 24);
+                t.level = (int)(f & 3); t.skip_even = (int)((f >> 2) & 1); t.narrow = (int)((f >> 3) & 1); t.last = (int)((f >> 4) & 1);
+                const u64 k = tile_eval(sh, t, (int)(c >> 16) * 16);
+                key = k < key ? k : key;
+            }
+            if (t.last) {
+                if (threadIdx.x == 0) st.req_key[t.req] = key;
+                key = (0xffffffull << 32) | 0xffffffffull;
+            }
         }
         wave_sync(); // the arena is free again
         PROF(21);
-        t = nx;
+        par ^= 1;
+        nt = nn;
     }
 }
 
@@ -1377,6 +1454,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             }
 #ifdef SVT_ME_ABLATE
             if (SVT_ME_ABLATE == 2 && step == kC00) break;
+            if (SVT_ME_ABLATE >= 10 && step == SVT_ME_ABLATE - 10) break; // stop in front of stage (SVT_ME_ABLATE - 10): 11 = after zz, 12 = after pre-HME, 13 = after L0, 14 = after L1
             if (SVT_ME_ABLATE == 4 && run && step < kProbe) { step = step == kPrehme ? kL0 : step + 1; bi = 0; continue; } // no HME searches, no post
             if (SVT_ME_ABLATE == 5 && run && step < kProbe) st.nreq = 0;
 #endif
@@ -1424,7 +1502,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
 
 
 #ifdef SVT_ME_ABLATE
-        if (SVT_ME_ABLATE == 2 || SVT_ME_ABLATE == 3) continue;
+        if (SVT_ME_ABLATE == 2 || SVT_ME_ABLATE == 3 || SVT_ME_ABLATE >= 10) continue;
 #endif
         // ---- me_prune_ref (motion_estimation.c:1522-1565) ----------------------------------------------------
         if (c.enable_hme_flag && c.enable_me_hme_ref_pruning && !mctf) {

@@ -51,11 +51,21 @@ __device__ __forceinline__ int32_t rshift64(i64 v, int bit) { return (int32_t)((
 // < 2^19 behind the reference's own stage clamps (clamp_value to bd + 8 / 16..18 bits) -- so the full-rate v_mul_i32_i24
 // returns the same low 32 bits as the quarter-rate v_mul_lo_u32.  Forward transforms keep the 32-bit multiply: their
 // data range depends on the caller's samples.
+// MUL == 2: the caller has bounded the data so that |a| + |b| < 2^18 (weights <= 2^13): neither product wraps and their sum with the rounding
+// term stays below 2^31, so the whole butterfly is three full-rate 32-bit instructions with the reference's exact result.
 template <int MUL> __device__ __forceinline__ int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b, int bit) {
+    if constexpr (MUL == 2) return (__mul24(w1, b) + (__mul24(w0, a) + (1 << (bit - 1)))) >> bit; // two v_mad_i32_i24 + a shift
     i64 s;
     if constexpr (MUL == 1) s = (i64)__mul24(w0, a) + (i64)__mul24(w1, b);
     else s = (i64)(int32_t)((uint32_t)w0 * (uint32_t)a) + (i64)(int32_t)((uint32_t)w1 * (uint32_t)b);
     return (int32_t)((s + ((i64)1 << (bit - 1))) >> bit);
+}
+// clamp_value of a SUM or DIFFERENCE inside an inverse pass.  The reference widens to 64 bits before it clamps; here the operands are at most
+// 20-bit numbers -- the pass inputs are clamped to bd + 8 / 16 bits on entry, every butterfly output is clamped again, and a half_btf output is
+// below sqrt(2) times its inputs -- so the 32-bit sum is the same number and the clamp is one v_med3_i32.
+__device__ __forceinline__ int32_t clamp32(int32_t v, int bit) {
+    const int32_t hi = (1 << (bit - 1)) - 1, lo = -(1 << (bit - 1));
+    return v < lo ? lo : (v > hi ? hi : v);
 }
 __device__ __forceinline__ int32_t clampv(i64 v, int bit) {
     const i64 hi = ((i64)1 << (bit - 1)) - 1, lo = -((i64)1 << (bit - 1));
@@ -114,7 +124,7 @@ template <int M, int K, int CLAMP> __device__ __forceinline__ void odd_bfly(int3
             const int32_t lo = x[i0], hi = x[i1];
             int32_t s, d;
             if constexpr (CLAMP < 0) { s = wadd(lo, hi); d = (g & 1) ? wsub(hi, lo) : wsub(lo, hi); }
-            else { s = clampv((i64)lo + hi, CLAMP); d = clampv((g & 1) ? (i64)hi - lo : (i64)lo - hi, CLAMP); }
+            else { s = clamp32(lo + hi, CLAMP); d = clamp32((g & 1) ? hi - lo : lo - hi, CLAMP); }
             x[i0] = (g & 1) ? d : s;
             x[i1] = (g & 1) ? s : d;
         }
@@ -129,12 +139,12 @@ template <int M, bool INV, int MUL = INV ? 1 : 0> __device__ __forceinline__ voi
         else { x[p] = hbtf<MUL>(c[A], a, -c[B], b, bit); x[m] = hbtf<MUL>(c[B], a, c[A], b, bit); }
     }
 }
-template <int M, int K> struct OddFwd {
+template <int M, int K, int FM> struct OddFwd {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
         if constexpr (K < ilog2c(M)) {
-            odd_rot<M, K, 0>(x, c, bit);
+            odd_rot<M, K, FM>(x, c, bit);
             odd_bfly<M, K, -1>(x);
-            OddFwd<M, K + 1>::run(x, c, bit);
+            OddFwd<M, K + 1, FM>::run(x, c, bit);
         }
     }
 };
@@ -147,18 +157,20 @@ template <int M, int K, int CLAMP> struct OddInv {
         }
     }
 };
-template <int N> __device__ __forceinline__ void fdct_core(int32_t *x, const int32_t *c, int bit) {
+// FM (forward multiply mode): 0 = 32-bit wrapping products (any input), 1 = full-rate 24-bit multiplies -- exact whenever every node of the
+// pass fits 24 signed bits, which the callers establish from the block's largest residual (see fwd_mul24_safe)
+template <int N, int FM> __device__ __forceinline__ void fdct_core(int32_t *x, const int32_t *c, int bit) {
     if constexpr (N == 2) {
         const int32_t a = x[0], b = x[1];
-        x[0] = hbtf<0>(c[32], a, c[32], b, bit);
-        x[1] = hbtf<0>(-c[32], b, c[32], a, bit);
+        x[0] = hbtf<FM>(c[32], a, c[32], b, bit);
+        x[1] = hbtf<FM>(-c[32], b, c[32], a, bit);
     } else {
         constexpr int M = N / 2;
 #pragma unroll
         for (int i = 0; i < M; i++) { const int32_t a = x[i], b = x[N - 1 - i]; x[i] = wadd(a, b); x[N - 1 - i] = wsub(a, b); }
-        fdct_core<M>(x, c, bit);
-        OddFwd<M, 1>::run(x, c, bit);
-        odd_final<M, false, 0>(x, c, bit);
+        fdct_core<M, FM>(x, c, bit);
+        OddFwd<M, 1, FM>::run(x, c, bit);
+        odd_final<M, false, FM>(x, c, bit);
     }
 }
 template <int N, int CLAMP> __device__ __forceinline__ void idct_core(int32_t *x, const int32_t *c, int bit) {
@@ -172,7 +184,7 @@ template <int N, int CLAMP> __device__ __forceinline__ void idct_core(int32_t *x
         OddInv<M, ilog2c(M) - 1, CLAMP>::run(x, c, bit);
         idct_core<M, CLAMP>(x, c, bit);
 #pragma unroll
-        for (int i = 0; i < M; i++) { const int32_t a = x[i], b = x[N - 1 - i]; x[i] = clampv((i64)a + b, CLAMP); x[N - 1 - i] = clampv((i64)a - b, CLAMP); }
+        for (int i = 0; i < M; i++) { const int32_t a = x[i], b = x[N - 1 - i]; x[i] = clamp32(a + b, CLAMP); x[N - 1 - i] = clamp32(a - b, CLAMP); }
     }
 }
 template <int N> __device__ __forceinline__ void permute_brev(int32_t *x) { // out[k] = in[brev(k)]: an involution, swap pairs
@@ -216,7 +228,7 @@ template <int N, int HH, int CLAMP> __device__ __forceinline__ void adst_bfly(in
         for (int j = 0; j < HH; j++) {
             const int32_t a = x[b + j], d = x[b + j + HH];
             if constexpr (CLAMP < 0) { x[b + j] = wadd(a, d); x[b + j + HH] = wsub(a, d); }
-            else { x[b + j] = clampv((i64)a + d, CLAMP); x[b + j + HH] = clampv((i64)a - d, CLAMP); }
+            else { x[b + j] = clamp32(a + d, CLAMP); x[b + j + HH] = clamp32(a - d, CLAMP); }
         }
 }
 template <int N, int MUL> __device__ __forceinline__ void adst_last(int32_t *x, const int32_t *c, int bit) {
@@ -228,9 +240,9 @@ template <int N, int MUL> __device__ __forceinline__ void adst_last(int32_t *x, 
         x[2 * j + 1] = hbtf<MUL>(c[B], a, -c[A], d, bit);
     }
 }
-template <int N, int HH> struct AdstFwd {
+template <int N, int HH, int FM> struct AdstFwd {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
-        if constexpr (HH < N) { adst_rot<N, HH, 0>(x, c, bit); adst_bfly<N, HH, -1>(x); AdstFwd<N, HH * 2>::run(x, c, bit); }
+        if constexpr (HH < N) { adst_rot<N, HH, FM>(x, c, bit); adst_bfly<N, HH, -1>(x); AdstFwd<N, HH * 2, FM>::run(x, c, bit); }
     }
 };
 template <int N, int HH, int CLAMP> struct AdstInv {
@@ -238,12 +250,12 @@ template <int N, int HH, int CLAMP> struct AdstInv {
         if constexpr (HH >= 2) { adst_bfly<N, HH, CLAMP>(x); adst_rot<N, HH, 1>(x, c, bit); AdstInv<N, HH / 2, CLAMP>::run(x, c, bit); }
     }
 };
-template <int N> __device__ __forceinline__ void fadst(int32_t *x, const int32_t *c, int bit) {
+template <int N, int FM> __device__ __forceinline__ void fadst(int32_t *x, const int32_t *c, int bit) {
     int32_t y[N];
 #pragma unroll
     for (int k = 0; k < N; k++) { const int32_t v = x[adst_perm<N>(k)]; y[k] = (__builtin_popcount(k) & 1) ? (int32_t)(0u - (uint32_t)v) : v; }
-    AdstFwd<N, 2>::run(y, c, bit);
-    adst_last<N, 0>(y, c, bit);
+    AdstFwd<N, 2, FM>::run(y, c, bit);
+    adst_last<N, FM>(y, c, bit);
 #pragma unroll
     for (int j = 0; j < N / 2; j++) { x[2 * j] = y[2 * j + 1]; x[2 * j + 1] = y[N - 2 - 2 * j]; }
 }
@@ -284,13 +296,20 @@ template <int N> __device__ __forceinline__ void identity(int32_t *x) { // trans
     }
 }
 // 1-D dispatch: type 0 DCT, 1/2 ADST (flips are applied by the 2-D passes), 3 identity.  Wave-uniform switch.
-template <int N> __device__ __forceinline__ void fwd_1d(int32_t *x, int type, int bit) {
+template <int N, int FM> __device__ __forceinline__ void fwd_1d(int32_t *x, int type, int bit) {
     const int32_t *c = c_cospi[bit - 10];
     if (type == 3) identity<N>(x);
-    else if (type == 0) { fdct_core<N>(x, c, bit); permute_brev<N>(x); }
+    else if (type == 0) { fdct_core<N, FM>(x, c, bit); permute_brev<N>(x); }
     else if constexpr (N == 4) adst4(x, bit, false);
-    else if constexpr (N <= 16) fadst<N>(x, c, bit);
+    else if constexpr (N <= 16) fadst<N, FM>(x, c, bit);
 }
+// A block's forward transform may use the 24-bit multiplies when |residual| <= 4095: a node of a 1-D pass is a sum of at most N inputs of that
+// pass with weights of magnitude <= 1, so with the up-shift of at most 2 in front of the column pass and the down-shifts between the passes
+// (fwd_txfm_shift_ls, transforms.h:27-45) no node of any of the 19 sizes exceeds 64 * 65,520 < 2^22; the cosine weights are < 2^14.  Any
+// 8- / 10-bit picture satisfies it; samples outside the bit depth (the reference accepts any uint16) take the 32-bit path.
+constexpr int kFwdMul24MaxResidual = 4095;
+// The three-instruction butterflies (hbtf<2>) need every node of the pass below 2^17: N x the largest input of the pass (measured over the wave).
+__device__ __forceinline__ bool pass_fits_17_bits(uint32_t wave_max_abs_input, int n) { return (unsigned long long)wave_max_abs_input * (unsigned)n < (1u << 17); }
 template <int N, int CLAMP> __device__ __forceinline__ void inv_1d(int32_t *x, int type) {
     const int32_t *c = c_cospi[2]; // INV_COS_BIT = 12
     if (type == 3) identity<N>(x);
@@ -398,33 +417,44 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     // runs of RUN samples per (unaligned) vector load: the planes' offsets and strides are the caller's
     constexpr int RUN = W < 8 ? W : 8, RPR = W / RUN; // run length, runs per row
     typedef Pix __attribute__((ext_vector_type(RUN), aligned(sizeof(Pix)))) RunU;
+    uint32_t rmax = 0; // largest |residual| this lane produced
     for (int i = l; i < RPR * H; i += LW) {
         const int r = i / RPR, c = (i - r * RPR) * RUN;
         const RunU sv = *reinterpret_cast<const RunU *>(src + (size_t)r * p.d.src_stride + c);
         const RunU pv = *reinterpret_cast<const RunU *>(pred + (size_t)r * p.d.pred_stride + c);
 #pragma unroll
-        for (int k = 0; k < RUN; k++) A[r * PA + c + k] = (int16_t)((int16_t)sv[k] - (int16_t)pv[k]);
+        for (int k = 0; k < RUN; k++) {
+            const int32_t d = (int16_t)((int16_t)sv[k] - (int16_t)pv[k]);
+            A[r * PA + c + k] = d;
+            rmax = max(rmax, (uint32_t)(d < 0 ? -d : d));
+        }
     }
+    // one answer for the wave (all its blocks): every residual small enough for the 24-bit multiplies of the forward passes?
+    // one answer for the wave (all its blocks): small enough data for the three-instruction butterflies?  The column pass sees the residual
+    // shifted up by fsh[0] (0 or 2)
+    const bool fast_col = pass_fits_17_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(rmax)) << (fsh[0] > 0 ? fsh[0] : 0), H);
     __syncthreads();
     // forward columns (av1_tranform_two_d_core_c, transforms.c:2287-2308)
+    uint32_t cmax = 0; // largest |column output| of this lane
     if (l < W) {
         int32_t x[H];
 #pragma unroll
         for (int r = 0; r < H; r++) x[r] = A[(ud ? H - 1 - r : r) * PA + l];
         shift_vec<H>(x, fsh[0]);
-        fwd_1d<H>(x, vt, bit_col);
+        if (fast_col) fwd_1d<H, 2>(x, vt, bit_col); else fwd_1d<H, 0>(x, vt, bit_col); // wave-uniform
         shift_vec<H>(x, fsh[1]);
         const int oc = lr ? W - 1 - l : l;
 #pragma unroll
-        for (int r = 0; r < H; r++) A[r * PA + oc] = x[r];
+        for (int r = 0; r < H; r++) { A[r * PA + oc] = x[r]; cmax = max(cmax, (uint32_t)(x[r] < 0 ? -x[r] : x[r])); }
     }
+    const bool fast_row = pass_fits_17_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(cmax)), W); // the row pass's input
     __syncthreads();
     // forward rows (:2310-2323)
     if (l < H) {
         int32_t x[W];
 #pragma unroll
         for (int c = 0; c < W; c++) x[c] = A[l * PA + c];
-        fwd_1d<W>(x, ht, bit_row);
+        if (fast_row) fwd_1d<W, 2>(x, ht, bit_row); else fwd_1d<W, 0>(x, ht, bit_row);
         shift_vec<W>(x, fsh[2]);
         if constexpr (RECT) {
 #pragma unroll
@@ -689,25 +719,36 @@ template <int TS> __global__ void __launch_bounds__(64, rd_waves_per_simd(TS)) f
     const int16_t *res = p.d.residual + jb.src_offset;
     const int8_t *fsh = c_fwd_shift[TS];
     const int bit_col = c_fwd_cos_col[ilog2c(W) - 2][ilog2c(H) - 2], bit_row = c_fwd_cos_row[ilog2c(W) - 2][ilog2c(H) - 2];
-    for (int i = l; i < W * H; i += LW) { const int r = i / W, c = i - r * W; A[r * PA + c] = res[(size_t)r * p.d.residual_stride + c]; }
+    uint32_t rmax = 0;
+    for (int i = l; i < W * H; i += LW) {
+        const int r = i / W, c = i - r * W;
+        const int32_t d = res[(size_t)r * p.d.residual_stride + c];
+        A[r * PA + c] = d;
+        rmax = max(rmax, (uint32_t)(d < 0 ? -d : d));
+    }
+    // one answer for the wave (all its blocks): small enough data for the three-instruction butterflies?  The column pass sees the residual
+    // shifted up by fsh[0] (0 or 2)
+    const bool fast_col = pass_fits_17_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(rmax)) << (fsh[0] > 0 ? fsh[0] : 0), H); // see kFwdMul24MaxResidual
     __syncthreads();
+    uint32_t cmax = 0;
     if (l < W) { // columns (:2287-2308)
         int32_t x[H];
 #pragma unroll
         for (int r = 0; r < H; r++) x[r] = A[(ud ? H - 1 - r : r) * PA + l];
         shift_vec<H>(x, fsh[0]);
-        fwd_1d<H>(x, vt, bit_col);
+        if (fast_col) fwd_1d<H, 2>(x, vt, bit_col); else fwd_1d<H, 0>(x, vt, bit_col); // wave-uniform
         shift_vec<H>(x, fsh[1]);
         const int oc = lr ? W - 1 - l : l;
 #pragma unroll
-        for (int r = 0; r < H; r++) A[r * PA + oc] = x[r];
+        for (int r = 0; r < H; r++) { A[r * PA + oc] = x[r]; cmax = max(cmax, (uint32_t)(x[r] < 0 ? -x[r] : x[r])); }
     }
+    const bool fast_row = pass_fits_17_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(cmax)), W); // the row pass's input
     __syncthreads();
     if (l < H) { // rows (:2310-2323)
         int32_t x[W];
 #pragma unroll
         for (int c = 0; c < W; c++) x[c] = A[l * PA + c];
-        fwd_1d<W>(x, ht, bit_row);
+        if (fast_row) fwd_1d<W, 2>(x, ht, bit_row); else fwd_1d<W, 0>(x, ht, bit_row);
         shift_vec<W>(x, fsh[2]);
         if constexpr (RECT) {
 #pragma unroll
