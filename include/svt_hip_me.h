@@ -176,6 +176,10 @@ const char *svt_hip_last_error(const SvtHipContext *ctx);
 /* stream used by this context (hipStream_t as void*); callers that own HIP events time on it */
 void *svt_hip_context_stream(SvtHipContext *ctx);
 int   svt_hip_context_sync(SvtHipContext *ctx);
+/* Upper limit of the persistent ME waves per CU of this context's launches (0 = as many as fit, the default).  A pipeline that runs the
+ * mode-decision kernels of earlier pictures on another context's stream beside the ME launch -- as the reference runs its ME and
+ * mode-decision processes side by side -- lowers it so that both find LDS and registers on every CU. */
+int   svt_hip_context_set_me_waves_per_cu(SvtHipContext *ctx, uint32_t waves);
 
 /* ---- preset derivation (host only) ---- */
 /* Restates svt_aom_sig_deriv_me + svt_aom_sig_deriv_multi_processes' HME flags (enc_mode_config.c:138-833,1632-1642). */

@@ -5,13 +5,14 @@
 #include "../../include/svt_hip_me.h"
 
 // Shape of the ME kernel (tunable at build time): one wave per 64x64 block; waves per SIMD the launch bounds plan for
-// (3 -> 168 VGPRs, at most 12 blocks in flight per CU) and the LDS window arena each wave owns (the integer search needs
-// 64 + 2 rows of 96 .. 112 bytes at least: 8 KiB).
+// (2 -> 256 VGPRs, 8 blocks in flight per CU, no register spills; 3 -> 168 VGPRs, 12 blocks, 35 spilled registers and 1.5 % more ME time)
+// and the LDS window arena each wave owns (the integer search needs 64 + 2 rows of 96 .. 112 bytes at least: 8 KiB; measured at 2 waves
+// per SIMD: 9 / 10 KiB 2.94 ms per launch of the bench, 12 / 14 KiB 3.25 ms -- the eighth wave of a CU no longer fits its LDS).
 #ifndef SVT_HIP_ME_WAVES_PER_SIMD
-#define SVT_HIP_ME_WAVES_PER_SIMD 3
+#define SVT_HIP_ME_WAVES_PER_SIMD 2
 #endif
 #ifndef SVT_HIP_ME_WIN_BYTES
-#define SVT_HIP_ME_WIN_BYTES 8192
+#define SVT_HIP_ME_WIN_BYTES 10240
 #endif
 #define SVT_HIP_ME_QUEUES 8 /* one b64 band queue per XCD */
 

@@ -1765,6 +1765,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift).total + 127) & ~(size_t)127;
     uint32_t per_cu = (uint32_t)((160u * 1024u) / lds);
     if (per_cu > 4u * SVT_HIP_ME_WAVES_PER_SIMD) per_cu = 4u * SVT_HIP_ME_WAVES_PER_SIMD;
+    if (ctx->me_waves_per_cu && per_cu > ctx->me_waves_per_cu) per_cu = ctx->me_waves_per_cu; // the caller leaves room for kernels of another stream
     uint32_t grid = (uint32_t)ctx->num_cus * per_cu;
     if (grid > total) grid = total;
     const int slot = lane->ring_next;
@@ -1778,5 +1779,11 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(64), lds, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
                        reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES));
     SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_context_set_me_waves_per_cu(SvtHipContext *ctx, uint32_t waves) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    ctx->me_waves_per_cu = waves;
     return SVT_HIP_OK;
 }

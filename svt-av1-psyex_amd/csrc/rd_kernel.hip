@@ -45,6 +45,13 @@ __device__ const uint8_t c_log_scale[19]     = {0, 0, 0, 1, 2, 0, 0, 0, 0, 1, 1,
 __device__ const uint8_t c_vtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};
 __device__ const uint8_t c_htx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};
 
+// ((int64)a * b) >> sh (0 < sh < 32) for operands that fit 24 signed bits, low 32 bits of the result: three full-rate instructions
+// (v_mul_i32_i24, v_mul_hi_i32_i24, v_alignbit_b32) instead of the quarter-rate 32 x 32 -> 64 multiply
+__device__ __forceinline__ int32_t mul24_shr(int32_t a, int32_t b, int sh) {
+    int32_t hi;
+    asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    return (int32_t)__builtin_amdgcn_alignbit((uint32_t)hi, (uint32_t)__mul24(a, b), (uint32_t)sh);
+}
 __device__ __forceinline__ int32_t rshift64(i64 v, int bit) { return (int32_t)((v + ((i64)1 << (bit - 1))) >> bit); }
 // half_btf of the reference (Codec/transforms.h / inv_transforms.h): two 32-bit wrapping products, summed and rounded in
 // 64 bits.  MUL == 1 (inverse transforms): both operands of every product fit 24 signed bits -- cos weights < 2^13, data
@@ -148,12 +155,12 @@ template <int M, int K, int FM> struct OddFwd {
         }
     }
 };
-template <int M, int K, int CLAMP> struct OddInv {
+template <int M, int K, int CLAMP, int IM> struct OddInv {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
         if constexpr (K >= 1) {
             odd_bfly<M, K, CLAMP>(x);
-            odd_rot<M, K, 1>(x, c, bit);
-            OddInv<M, K - 1, CLAMP>::run(x, c, bit);
+            odd_rot<M, K, IM>(x, c, bit);
+            OddInv<M, K - 1, CLAMP, IM>::run(x, c, bit);
         }
     }
 };
@@ -173,16 +180,18 @@ template <int N, int FM> __device__ __forceinline__ void fdct_core(int32_t *x, c
         odd_final<M, false, FM>(x, c, bit);
     }
 }
-template <int N, int CLAMP> __device__ __forceinline__ void idct_core(int32_t *x, const int32_t *c, int bit) {
+// IM (inverse multiply mode): 1 = 24-bit products summed in 64 bits (any clamped input), 2 = the three-instruction butterflies, exact while
+// every node of the pass is below 2^18 (weights <= 2^12): the callers measure the pass input
+template <int N, int CLAMP, int IM> __device__ __forceinline__ void idct_core(int32_t *x, const int32_t *c, int bit) {
     if constexpr (N == 2) {
         const int32_t a = x[0], b = x[1];
-        x[0] = hbtf<1>(c[32], a, c[32], b, bit);
-        x[1] = hbtf<1>(c[32], a, -c[32], b, bit);
+        x[0] = hbtf<IM>(c[32], a, c[32], b, bit);
+        x[1] = hbtf<IM>(c[32], a, -c[32], b, bit);
     } else {
         constexpr int M = N / 2;
-        odd_final<M, true, 1>(x, c, bit);
-        OddInv<M, ilog2c(M) - 1, CLAMP>::run(x, c, bit);
-        idct_core<M, CLAMP>(x, c, bit);
+        odd_final<M, true, IM>(x, c, bit);
+        OddInv<M, ilog2c(M) - 1, CLAMP, IM>::run(x, c, bit);
+        idct_core<M, CLAMP, IM>(x, c, bit);
 #pragma unroll
         for (int i = 0; i < M; i++) { const int32_t a = x[i], b = x[N - 1 - i]; x[i] = clamp32(a + b, CLAMP); x[N - 1 - i] = clamp32(a - b, CLAMP); }
     }
@@ -245,9 +254,9 @@ template <int N, int HH, int FM> struct AdstFwd {
         if constexpr (HH < N) { adst_rot<N, HH, FM>(x, c, bit); adst_bfly<N, HH, -1>(x); AdstFwd<N, HH * 2, FM>::run(x, c, bit); }
     }
 };
-template <int N, int HH, int CLAMP> struct AdstInv {
+template <int N, int HH, int CLAMP, int IM> struct AdstInv {
     static __device__ __forceinline__ void run(int32_t *x, const int32_t *c, int bit) {
-        if constexpr (HH >= 2) { adst_bfly<N, HH, CLAMP>(x); adst_rot<N, HH, 1>(x, c, bit); AdstInv<N, HH / 2, CLAMP>::run(x, c, bit); }
+        if constexpr (HH >= 2) { adst_bfly<N, HH, CLAMP>(x); adst_rot<N, HH, IM>(x, c, bit); AdstInv<N, HH / 2, CLAMP, IM>::run(x, c, bit); }
     }
 };
 template <int N, int FM> __device__ __forceinline__ void fadst(int32_t *x, const int32_t *c, int bit) {
@@ -259,12 +268,12 @@ template <int N, int FM> __device__ __forceinline__ void fadst(int32_t *x, const
 #pragma unroll
     for (int j = 0; j < N / 2; j++) { x[2 * j] = y[2 * j + 1]; x[2 * j + 1] = y[N - 2 - 2 * j]; }
 }
-template <int N, int CLAMP> __device__ __forceinline__ void iadst(int32_t *x, const int32_t *c, int bit) {
+template <int N, int CLAMP, int IM> __device__ __forceinline__ void iadst(int32_t *x, const int32_t *c, int bit) {
     int32_t y[N];
 #pragma unroll
     for (int j = 0; j < N / 2; j++) { y[2 * j + 1] = x[2 * j]; y[N - 2 - 2 * j] = x[2 * j + 1]; }
-    adst_last<N, 1>(y, c, bit);
-    AdstInv<N, N / 2, CLAMP>::run(y, c, bit);
+    adst_last<N, IM>(y, c, bit);
+    AdstInv<N, N / 2, CLAMP, IM>::run(y, c, bit);
 #pragma unroll
     for (int k = 0; k < N; k++) x[adst_perm<N>(k)] = (__builtin_popcount(k) & 1) ? (int32_t)(0u - (uint32_t)y[k]) : y[k];
 }
@@ -310,12 +319,21 @@ template <int N, int FM> __device__ __forceinline__ void fwd_1d(int32_t *x, int 
 constexpr int kFwdMul24MaxResidual = 4095;
 // The three-instruction butterflies (hbtf<2>) need every node of the pass below 2^17: N x the largest input of the pass (measured over the wave).
 __device__ __forceinline__ bool pass_fits_17_bits(uint32_t wave_max_abs_input, int n) { return (unsigned long long)wave_max_abs_input * (unsigned)n < (1u << 17); }
-template <int N, int CLAMP> __device__ __forceinline__ void inv_1d(int32_t *x, int type) {
+template <int N, int CLAMP, int IM> __device__ __forceinline__ void inv_1d(int32_t *x, int type) {
     const int32_t *c = c_cospi[2]; // INV_COS_BIT = 12
     if (type == 3) identity<N>(x);
-    else if (type == 0) { permute_brev<N>(x); idct_core<N, CLAMP>(x, c, 12); }
+    else if (type == 0) { permute_brev<N>(x); idct_core<N, CLAMP, IM>(x, c, 12); }
     else if constexpr (N == 4) adst4(x, 12, true);
-    else if constexpr (N <= 16) iadst<N, CLAMP>(x, c, 12);
+    else if constexpr (N <= 16) iadst<N, CLAMP, IM>(x, c, 12);
+}
+// every node of an inverse pass is a sum of at most N pass inputs with weights of magnitude <= 1 (the stage clamps only shrink it): below 2^18
+// when N x the largest |input| is
+__device__ __forceinline__ bool ipass_fits_18_bits(uint32_t wave_max_abs_input, int n) { return (unsigned long long)wave_max_abs_input * (unsigned)n < (1u << 18); }
+template <int N> __device__ __forceinline__ uint32_t vec_max_abs(const int32_t *x) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) m = max(m, (uint32_t)(x[i] < 0 ? -x[i] : x[i]));
+    return m;
 }
 template <int N> __device__ __forceinline__ void shift_vec(int32_t *x, int sh) { // svt_av1_round_shift_array_c(x, N, -sh)
     if (sh < 0) {
@@ -450,6 +468,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     const bool fast_row = pass_fits_17_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(cmax)), W); // the row pass's input
     __syncthreads();
     // forward rows (:2310-2323)
+    uint32_t comax = 0; // largest |coefficient| of this lane
     if (l < H) {
         int32_t x[W];
 #pragma unroll
@@ -462,7 +481,10 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         }
 #pragma unroll
         for (int c = 0; c < W; c++) A[l * PA + c] = x[c];
+        comax = vec_max_abs<W>(x);
     }
+    // coefficients below 2^16 in every block of the wave: the quantizer's products fit 24-bit multiplies (see the loop below)
+    const bool q24 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(comax)) < (1u << 16);
     __syncthreads();
     // 64-point sizes keep the top-left 32x32 (svt_handle_transform*_c, transforms.c:2374-2505)
     // partial-frequency shapes (av1_estimate_transform_N2 / _N4 / _ONLY_DC, transforms.c:2633-2948): the pruned 1-D kernels
@@ -502,7 +524,26 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         satd += (uint32_t)a;
         int32_t qv = 0, dq = 0;
         const int32_t wt = qm ? qm[rc] : 32, iwt = qm ? iqm[rc] : 32; // AOM_QM_BITS = 5
-        if (p.d.quant_kind == 0 && !qm) { // the same "b" quantizer with the flat matrix (wt = iwt = 32), in 32-bit arithmetic:
+        if (q24 && !qm) { // either quantizer with the flat matrix while |coeff| < 2^16 (wave-uniform): every product has 24-bit operands
+            // "b": t = |coeff| + round < 2^17; (t << 5) * quant >> 16 == t * quant >> 11; tmp = that + (t << 5) lies in t * [16, 48) < 2^23
+            if (p.d.quant_kind == 0) {
+                if (a >= zb_c[ac]) {
+                    int32_t t = a + rnd_c[ac];
+                    if (BD == 8) t = t > 32767 ? 32767 : t;
+                    const int32_t tmp = mul24_shr(t, q.quant[ac], 11) + (t << 5);
+                    qv = mul24_shr(tmp, q.quant_shift[ac], 21 - log_scale);
+                    dq = __mul24(qv, (int32_t)q.dequant[ac]) >> log_scale;
+                }
+            } else { // "fp": (|coeff| + round_fp) * quant_fp >> (16 - log_scale)
+                const bool keep = (a << (1 + log_scale)) >= q.dequant[ac];
+                if (keep) {
+                    int32_t t = a + (log_scale ? ((q.round_fp[ac] + (1 << (log_scale - 1))) >> log_scale) : q.round_fp[ac]);
+                    if (BD == 8) t = t < -32768 ? -32768 : (t > 32767 ? 32767 : t);
+                    qv = mul24_shr(t, q.quant_fp[ac], 16 - log_scale);
+                    dq = __mul24(qv, (int32_t)q.dequant[ac]) >> log_scale;
+                }
+            }
+        } else if (p.d.quant_kind == 0 && !qm) { // the same "b" quantizer with the flat matrix (wt = iwt = 32), in 32-bit arithmetic:
             // |coeff| < 2^24 for any int16 residual (forward gain <= N per pass, minus the stage shifts), so (|coeff| + round) << 5
             // and its products' high parts fit 32 bits; every intermediate equals the reference's 64-bit value
             const int32_t zb = zb_c[ac];
@@ -560,19 +601,27 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     dpred = seg_sum_u64<LW>(dpred);
     __syncthreads();
     // inverse rows (inv_txfm2d_add_c, inv_transforms.c:2497-2511): discarded frequencies are zero
+    int32_t xr[W];
+    uint32_t irmax = 0; // largest |row-pass input| of this lane
     if (l < H) {
-        int32_t x[W];
 #pragma unroll
         for (int c = 0; c < W; c++) {
             int32_t v = (l < HP && c < WP) ? A[l * PB + c] : 0;
             if constexpr (RECT) v = rshift64((i64)v * 2896, 12);
-            x[c] = clampv(v, BD + 8);
+            xr[c] = clampv(v, BD + 8);
         }
-        inv_1d<W, ROW_CLAMP>(x, ht);
-        shift_vec<W>(x, c_inv_shift0[TS]);
-#pragma unroll
-        for (int c = 0; c < W; c++) A[l * PA + c] = x[c];
+        irmax = vec_max_abs<W>(xr);
     }
+    const bool fast_irow = ipass_fits_18_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(irmax)), W); // wave-uniform
+    uint32_t icmax = 0; // largest |row-pass output|: the column pass's input
+    if (l < H) {
+        if (fast_irow) inv_1d<W, ROW_CLAMP, 2>(xr, ht); else inv_1d<W, ROW_CLAMP, 1>(xr, ht);
+        shift_vec<W>(xr, c_inv_shift0[TS]);
+#pragma unroll
+        for (int c = 0; c < W; c++) A[l * PA + c] = xr[c];
+        icmax = vec_max_abs<W>(xr);
+    }
+    const bool fast_icol = ipass_fits_18_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(icmax)), H);
     __syncthreads();
     // inverse columns + reconstruction + SSE (:2513-2534; svt_spatial_full_distortion_kernel / 16-bit variant)
     u64 sse = 0;
@@ -581,7 +630,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         const int ic = lr ? W - 1 - l : l;
 #pragma unroll
         for (int r = 0; r < H; r++) x[r] = (r < HP) ? clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16) : 0; // rows >= 32 of a 64-row block are exactly zero after the row pass: constants, so the network prunes itself
-        inv_1d<H, COL_CLAMP>(x, vt);
+        if (fast_icol) inv_1d<H, COL_CLAMP, 2>(x, vt); else inv_1d<H, COL_CLAMP, 1>(x, vt);
         shift_vec<H>(x, -4);
         // residual (with the vertical flip undone) back to LDS, row-major: the reconstruction below moves whole runs
 #pragma unroll
@@ -647,26 +696,34 @@ template <int TS, int BD, typename Pix> __global__ void __launch_bounds__(64, rd
     const int32_t *dq = p.d.dqcoeff + (size_t)(valid ? job : 0) * NP;
     for (int rc = l; rc < NP; rc += LW) { const int r = rc / WP, c = rc - r * WP; A[r * PB + c] = dq[rc]; }
     __syncthreads();
+    int32_t xr[W];
+    uint32_t irmax = 0; // largest |row-pass input| of this lane
     if (l < H) { // inverse rows (:2497-2511)
-        int32_t x[W];
 #pragma unroll
         for (int c = 0; c < W; c++) {
             int32_t v = (l < HP && c < WP) ? A[l * PB + c] : 0;
             if constexpr (RECT) v = rshift64((i64)v * 2896, 12);
-            x[c] = clampv(v, BD + 8);
+            xr[c] = clampv(v, BD + 8);
         }
-        inv_1d<W, ROW_CLAMP>(x, ht);
-        shift_vec<W>(x, c_inv_shift0[TS]);
-#pragma unroll
-        for (int c = 0; c < W; c++) A[l * PA + c] = x[c];
+        irmax = vec_max_abs<W>(xr);
     }
+    const bool fast_irow = ipass_fits_18_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(irmax)), W); // wave-uniform
+    uint32_t icmax = 0; // largest |row-pass output|: the column pass's input
+    if (l < H) {
+        if (fast_irow) inv_1d<W, ROW_CLAMP, 2>(xr, ht); else inv_1d<W, ROW_CLAMP, 1>(xr, ht);
+        shift_vec<W>(xr, c_inv_shift0[TS]);
+#pragma unroll
+        for (int c = 0; c < W; c++) A[l * PA + c] = xr[c];
+        icmax = vec_max_abs<W>(xr);
+    }
+    const bool fast_icol = ipass_fits_18_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(icmax)), H);
     __syncthreads();
     if (l < W) { // inverse columns (:2513-2534)
         int32_t x[H];
         const int ic = lr ? W - 1 - l : l;
 #pragma unroll
         for (int r = 0; r < H; r++) x[r] = (r < HP) ? clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16) : 0;
-        inv_1d<H, COL_CLAMP>(x, vt);
+        if (fast_icol) inv_1d<H, COL_CLAMP, 2>(x, vt); else inv_1d<H, COL_CLAMP, 1>(x, vt);
         shift_vec<H>(x, -4);
 #pragma unroll
         for (int r = 0; r < H; r++) A[r * PA + l] = x[ud ? H - 1 - r : r];

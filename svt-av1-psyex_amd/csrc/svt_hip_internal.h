@@ -42,6 +42,7 @@ struct SvtHipContext {
     uint32_t    lane_busy;             // bit i: lane i is borrowed
     int16_t    *iscan_dev;             // [19][3][1024] inverse scan orders (rd_kernel.hip), this device's copy
     bool        me_attr_set;           // hipFuncSetAttribute done for the ME kernel on this device
+    uint32_t    me_waves_per_cu;       // 0: as many persistent ME waves per CU as fit; else an upper limit (svt_hip_context_set_me_waves_per_cu)
 };
 
 struct SvtHipPaPicture {
