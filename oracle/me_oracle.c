@@ -31,9 +31,21 @@
  * the global sum when the thread's orc_me_picture call returns. */
 static __thread uint64_t t_sad_ops;
 static uint64_t          g_sad_ops;
+/* the same count per stage of the block pipeline: 0 zero-MV SADs, 1 pre-HME, 2 / 3 / 4 HME level 0 / 1 / 2, 5 everything behind (centre checks,
+ * the 8x8-variance probe, the integer search) */
+enum { ORC_N_STAGES = 6 };
+static __thread int      t_stage;
+static __thread uint64_t t_stage_ops[ORC_N_STAGES];
+static uint64_t          g_stage_ops[ORC_N_STAGES];
 uint64_t orc_sad_ops(int reset) {
     const uint64_t v = __atomic_load_n(&g_sad_ops, __ATOMIC_RELAXED);
     if (reset) __atomic_store_n(&g_sad_ops, 0, __ATOMIC_RELAXED);
+    return v;
+}
+uint64_t orc_sad_ops_stage(int stage, int reset) {
+    if (stage < 0 || stage >= ORC_N_STAGES) return 0;
+    const uint64_t v = __atomic_load_n(&g_stage_ops[stage], __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(&g_stage_ops[stage], 0, __ATOMIC_RELAXED);
     return v;
 }
 
@@ -41,6 +53,7 @@ uint32_t orc_nxm_sad(const uint8_t *src, uint32_t src_stride, const uint8_t *ref
                      uint32_t width) {
     uint32_t acc = 0;
     t_sad_ops += (uint64_t)height * width;
+    t_stage_ops[t_stage] += (uint64_t)height * width;
     for (uint32_t r = 0; r < height; r++)
         for (uint32_t c = 0; c < width; c++) {
             int d = (int)src[r * src_stride + c] - (int)ref[r * ref_stride + c];
@@ -1033,6 +1046,7 @@ int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
     const uint32_t row0 = desc->b64_row_start, nrow = desc->b64_row_count ? desc->b64_row_count : h64 - row0;
     const uint32_t n_pu = svt_hip_me_n_pu(desc->enable_me_16x16, desc->enable_me_8x8);
     t_sad_ops = 0;
+    for (int i = 0; i < ORC_N_STAGES; i++) t_stage_ops[i] = 0;
     /* desc->aligned_* == ALIGN_POWER_OF_TWO(input width/height, 3) (motion_estimation.c:3093-3094, pcs.c:1496-1497) */
     const uint16_t aw = desc->aligned_width, ah = desc->aligned_height;
     for (uint32_t by = row0; by < row0 + nrow && by < h64; by++)
@@ -1063,15 +1077,21 @@ int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
                 }
             s->hme_l0_sa = cfg->hme_l0_sa;
             /* hme_b64: Codec/motion_estimation.c:2441-2475 */
+            t_stage = 0;
             if (cfg->me_early_exit_th || cfg->me_safe_limit_zz_th)
                 init_zz_sad(s);
+            t_stage = 1;
             if (cfg->prehme_enable)
                 prehme_b64(s);
             if (cfg->enable_hme_flag) {
+                t_stage = 2;
                 if (cfg->enable_hme_level0_flag) hme_level0_b64(s);
+                t_stage = 3;
                 if (cfg->enable_hme_level1_flag) hme_level12_b64(s, 1);
+                t_stage = 4;
                 if (cfg->enable_hme_level2_flag) hme_level12_b64(s, 2);
             }
+            t_stage = 5;
             set_final_search_centre(s);
             const int mctf    = cfg->me_type == 1;
             const int tf_exit = mctf && s->sr[0][0].hme_sad < desc->tf_me_exit_th; /* :3109-3113 */
@@ -1133,6 +1153,8 @@ int orc_me_picture(const SvtHipMeConfig *cfg, const SvtHipMePictureDesc *desc, c
         }
     free(s);
     __atomic_fetch_add(&g_sad_ops, t_sad_ops, __ATOMIC_RELAXED);
+    for (int i = 0; i < ORC_N_STAGES; i++) __atomic_fetch_add(&g_stage_ops[i], t_stage_ops[i], __ATOMIC_RELAXED);
+    t_stage = 0;
     return SVT_HIP_OK;
 }
 

@@ -5,7 +5,7 @@
 // search-centre selection, reference pruning, the 8x8-based integer search for 85 square PUs, candidate construction and the
 // per-block distortion scalars.  Workgroups are single waves: there is no workgroup barrier anywhere in the kernel, the
 // stages of a block are ordered by the wave's own program order, and a CU hides the latencies of one block's dependent
-// stages (global loads of the search windows, LDS round trips of the control code) behind the 10+ other blocks resident on it.
+// stages (global loads of the search windows, LDS round trips of the control code) behind the 7 other blocks resident on it.
 //
 // Mapping to the hardware:
 //   * persistent waves pull b64 jobs from eight band queues in HBM (one per XCD; a wave drains the queue of the XCD it
@@ -26,17 +26,21 @@
 #include "me_kernel.h"
 
 // Diagnostic build only (-DSVT_HIP_ME_PROFILE): lane 0 accumulates shader-clock deltas per phase (private array) and adds
-// them to queue_head[16 + 2*i] (u64) when the workgroup retires.  Never defined in the shipped library.
+// them to queue_head[16 + 2*i] (u64) when the wave retires.  Never defined in the shipped library.
 #ifdef SVT_HIP_ME_PROFILE
-struct Prof { unsigned long long acc[24], last; };
-#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < 24; i_++) prof_.acc[i_] = 0; prof_.last = clock64(); Prof *prof = &prof_
+struct Prof { unsigned long long acc[48], last; int step; };
+#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < 48; i_++) prof_.acc[i_] = 0; prof_.last = clock64(); prof_.step = 0; Prof *prof = &prof_
+#define PROF_STEP(s) (prof->step = (s))
+#define PROFS(i) PROF((i) + prof->step) /* per-stage slots: 24.. plan, 32.. staging, 40.. evaluation */
 #define PROF(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); prof->acc[i] += t_ - prof->last; prof->last = t_; } } while (0)
-#define PROF_FLUSH(ptr) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 24; i_++) atomicAdd((unsigned long long *)(ptr) + i_, prof->acc[i_]); } while (0)
+#define PROF_FLUSH(ptr) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 48; i_++) atomicAdd((unsigned long long *)(ptr) + i_, prof->acc[i_]); } while (0)
 #define PROF_PARAM , Prof *prof
 #define PROF_ARG , prof
 #else
 #define PROF_DECL do { } while (0)
 #define PROF(i) do { } while (0)
+#define PROFS(i) do { } while (0)
+#define PROF_STEP(s) do { } while (0)
 #define PROF_FLUSH(ptr) do { } while (0)
 #define PROF_PARAM
 #define PROF_ARG
@@ -81,17 +85,21 @@ struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
     int16_t        pad1;
 };
 
-// One tile of a round as the store / evaluation passes need it (the planning pass has the full geometry in scalar registers)
-constexpr int kRoundTiles = 8;
-struct __attribute__((aligned(8))) TileEnt {
-    int16_t  x0, y0, w, h;   // sub-area of the request's search area
-    uint16_t pitch, lds_vec; // LDS row pitch; first 16-byte vector of the tile in the arena
-    uint16_t nvec;           // vectors of the window
-    uint8_t  slot0, req;     // first register slot of its vectors while they are in flight; request index
-    uint8_t  bw, bh, rs, flags; // flags: level | skip_even << 2 | narrow << 3 | last << 4
-    uint32_t pad;
+// One tile of a stage's searches: a rectangle of a request's search area whose reference window fits the arena.  The tiles of a stage are
+// planned once, lane-parallel (plan_tiles), into St.tile[]; the load / store / evaluation passes of a round read their entries back as
+// wave-uniform values.
+constexpr int kMaxTiles = 40;
+struct __attribute__((aligned(16))) TileEnt {
+    const uint8_t *g0;       // global address of the window's first sample (search position (x0, y0), block row 0): LDS byte 0 of the tile
+    uint32_t stride;
+    int16_t  x0, y0;         // sub-area of the request's search area
+    int16_t  w, h;
+    uint16_t pitch, nvec;    // LDS row pitch (multiple of 16); 16-byte vectors of the window: (pitch / 16) * rows, rows contiguous in LDS
+    uint8_t  req, flags;     // request index; level | skip_even << 2 | narrow << 3 | last << 4
+    uint8_t  bw, bh;
+    uint8_t  rs, kd, km, pad; // 64 = kd * (pitch / 16) + km: how (row, vector) advance from one 64-vector pass to the next
 };
-static_assert(sizeof(TileEnt) == 24, "TileEnt is read as three 8-byte words");
+static_assert(sizeof(TileEnt) == 32, "TileEnt is read as two 16-byte words");
 
 struct MeReq { // integer search of one reference (open_loop_me_fullpel_search_sblock, motion_estimation.c:781-817)
     const uint8_t *pix0; // reference sample co-located with the block's top-left, MV (0,0)
@@ -133,7 +141,7 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
         struct { MeReq me[8], me_probe[8]; };
     };
     u64      req_key[kMaxReq];
-    TileEnt  tile[2][kRoundTiles];  // the tiles of the round in the arena and of the round on its way (see run_searches)
+    TileEnt  tile[kMaxTiles];       // the tiles of the current stage's searches (plan_tiles)
     uint32_t sadbuf[kNarrowMaxPos]; // per-position sums of a narrow (row-split) search
     int      nme, nprobe;
     uint32_t me_dist[85];
@@ -401,50 +409,82 @@ __device__ __forceinline__ u64 wave_min_key(uint32_t sad, uint32_t pos) {
     return ((u64)smin << 32) | pmin;
 }
 
-// One rectangle of a request's search area whose reference window fits the arena.  Every field is wave-uniform.
+// A tile entry in scalar registers.  Every field is wave-uniform.
 struct TileGeo {
-    const uint8_t *g0;     // global address of the window's first sample (search position (x0, y0), block row 0): LDS byte 0 of the tile
+    const uint8_t *g0;
     uint32_t stride;
-    int      req;          // request index, -1: no tile
-    int      x0, y0, w, h; // sub-area of the search area
-    int      pitch;        // LDS row pitch (multiple of 16)
-    int      nvec;         // 16-byte vectors of the window: (pitch / 16) * rows, rows contiguous in LDS
+    int      req;
+    int      x0, y0, w, h;
+    int      pitch, nvec;
     int      last;         // last tile of its request
     int      bw, bh, rs, level, skip_even, narrow;
-    int      kd, km;       // 64 = kd * (pitch / 16) + km: how (row, vector) advance from one 64-vector pass to the next
+    int      kd, km;
 };
 
-// Cursor over the tiles of st.req[0 .. nreq): a request is cut on a fixed (tw x th) grid chosen so that any of its tiles fits the arena
-struct TileCursor { int req, x, y, tw, th; };
+// inclusive prefix sum over lanes 0 .. 31 (rows 0 and 1 of the wave) by DPP: no LDS traffic
+__device__ __forceinline__ int scan32(int v) {
+#define SVT_SCAN_DPP(ctrl, rmask, bc) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xF, bc);
+    SVT_SCAN_DPP(0x111, 0xF, true)  // row_shr:1 (zero fill)
+    SVT_SCAN_DPP(0x112, 0xF, true)  // row_shr:2
+    SVT_SCAN_DPP(0x114, 0xF, true)  // row_shr:4
+    SVT_SCAN_DPP(0x118, 0xF, true)  // row_shr:8
+    SVT_SCAN_DPP(0x142, 0xA, false) // row_bcast:15 -> row 1 (and 3)
+#undef SVT_SCAN_DPP
+    return v;
+}
 
-__device__ __forceinline__ TileGeo next_tile(const St &st, int nreq, TileCursor &c) {
-    TileGeo t;
-    t.req = -1;
-    if (c.req >= nreq) return t;
-    const Req &rq = st.req[c.req];
-    Req r;
-    r.win = uni_ptr(rq.win); r.stride = uni(rq.stride);
-    r.sa_w = (int16_t)uni((uint32_t)rq.sa_w); r.sa_h = (int16_t)uni((uint32_t)rq.sa_h);
-    r.bw = (uint8_t)uni(rq.bw); r.bh = (uint8_t)uni(rq.bh); r.rs = (uint8_t)uni(rq.rs); r.level = (uint8_t)uni(rq.level); r.skip_even = (uint8_t)uni(rq.skip_even);
-    if (c.x == 0 && c.y == 0) {
-        int tw = r.sa_w, th = r.sa_h;
-        while (th > 1 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
-        while (tw > 8 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
-        c.tw = tw; c.th = th;
+// Plans the tiles of st.req[0 .. nreq) (nreq <= 32), lane <-> request: a request is cut on a fixed (tw x th) grid chosen so that any of its
+// tiles fits the arena (raster order over the grid); tile T of the stage's sequence goes to st.tile[T - t0] for T in [t0, t0 + kMaxTiles).
+// Returns the stage's tile count.
+__device__ __forceinline__ int plan_tiles(St &st, int nreq, int t0) {
+    const int lane = threadIdx.x;
+    int cnt = 0, tw = 8, th = 1, ntx = 1;
+    Req r = {};
+    if (lane < nreq) {
+        r = st.req[lane];
+        if (r.sa_w > 0 && r.sa_h > 0) {
+            tw = r.sa_w; th = r.sa_h;
+            while (th > 1 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
+            while (tw > 8 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
+            ntx = (int)div_by_rcp((uint32_t)(r.sa_w + tw - 1), rcp_of((uint32_t)tw));
+            cnt = ntx * (int)div_by_rcp((uint32_t)(r.sa_h + th - 1), rcp_of((uint32_t)th));
+        } else if (t0 == 0)
+            st.req_key[lane] = (0xffffffull << 32) | 0xffffffffull; // an empty search area: no position evaluated
     }
-    const int x0 = c.x, y0 = c.y, w = imin(c.tw, r.sa_w - x0), h = imin(c.th, r.sa_h - y0);
-    t.g0 = r.win + x0 + (long long)y0 * r.stride; t.stride = r.stride; t.req = c.req;
-    t.x0 = x0; t.y0 = y0; t.w = w; t.h = h;
-    t.pitch = (int)row_pitch(w, r.bw);
-    const int vpr = t.pitch >> 4;
-    t.nvec  = vpr * (h - 1 + (r.bh - 1) * r.rs + 1);
-    t.bw = r.bw; t.bh = r.bh; t.rs = r.rs; t.level = r.level; t.skip_even = r.skip_even;
-    t.narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
-    t.kd = (int)div_by_rcp(64u, rcp_of((uint32_t)vpr)); t.km = 64 - t.kd * vpr;
-    c.x = x0 + w;
-    if (c.x >= r.sa_w) { c.x = 0; c.y = y0 + h; }
-    t.last = 0;
-    if (c.y >= r.sa_h) { c.y = 0; c.req++; t.last = 1; }
+    const int incl = scan32(cnt), base = incl - cnt - t0;
+    const int total = __builtin_amdgcn_readlane(incl, 31);
+    const float ntx_rcp = rcp_of((uint32_t)ntx);
+    const int narrow = (r.sa_w * r.sa_h <= kNarrowMaxPos) ? 1 : 0;
+    for (int k = imax(0, -base); k < cnt && base + k < kMaxTiles; k++) { // divergent: a lane writes its own request's tiles
+        const int ty = (int)div_by_rcp((uint32_t)k, ntx_rcp), tx = k - ty * ntx;
+        const int x0 = tx * tw, y0 = ty * th, w = imin(tw, r.sa_w - x0), h = imin(th, r.sa_h - y0);
+        const int pitch = (int)row_pitch(w, r.bw), vpr = pitch >> 4;
+        const int kd = (int)div_by_rcp(64u, rcp_of((uint32_t)vpr));
+        TileEnt e;
+        e.g0 = r.win + x0 + (long long)y0 * r.stride; e.stride = r.stride;
+        e.x0 = (int16_t)x0; e.y0 = (int16_t)y0; e.w = (int16_t)w; e.h = (int16_t)h;
+        e.pitch = (uint16_t)pitch; e.nvec = (uint16_t)(vpr * (h - 1 + (r.bh - 1) * r.rs + 1));
+        e.req = (uint8_t)lane; e.flags = (uint8_t)(r.level | (r.skip_even << 2) | (narrow << 3) | ((k == cnt - 1) << 4));
+        e.bw = r.bw; e.bh = r.bh; e.rs = r.rs; e.kd = (uint8_t)kd; e.km = (uint8_t)(64 - kd * vpr); e.pad = 0;
+        st.tile[base + k] = e;
+    }
+    return total;
+}
+
+// tile entry i -> scalar registers (two 16-byte broadcast reads)
+__device__ __forceinline__ TileGeo read_tile(const St &st, int i) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(&st.tile[i]);
+    const uint4 b = *(reinterpret_cast<const uint4 *>(&st.tile[i]) + 1);
+    const uint32_t a0 = uni(a.x), a1 = uni(a.y), a2 = uni(a.z), a3 = uni(a.w), b0 = uni(b.x), b1 = uni(b.y), b2 = uni(b.z), b3 = uni(b.w);
+    TileGeo t;
+    t.g0 = reinterpret_cast<const uint8_t *>(((uintptr_t)a1 << 32) | a0); t.stride = a2;
+    t.x0 = (int16_t)(a3 & 0xFFFF); t.y0 = (int16_t)(a3 >> 16); t.w = (int16_t)(b0 & 0xFFFF); t.h = (int16_t)(b0 >> 16);
+    t.pitch = (int)(b1 & 0xFFFF); t.nvec = (int)(b1 >> 16);
+    t.req = (int)(b2 & 0xFF);
+    const int f = (int)((b2 >> 8) & 0xFF);
+    t.level = f & 3; t.skip_even = (f >> 2) & 1; t.narrow = (f >> 3) & 1; t.last = (f >> 4) & 1;
+    t.bw = (int)((b2 >> 16) & 0xFF); t.bh = (int)(b2 >> 24);
+    t.rs = (int)(b3 & 0xFF); t.kd = (int)((b3 >> 8) & 0xFF); t.km = (int)((b3 >> 16) & 0xFF);
     return t;
 }
 
@@ -456,16 +496,22 @@ typedef const __attribute__((address_space(1))) V4U GV4U;
 constexpr int kSmallVec = 128; // a tile of at most this many vectors takes two slots: four such tiles share a round
 template <int S0, int NS>
 __device__ __forceinline__ void tile_load(const TileGeo &t, V4 (&v)[kVecPerLane]) {
-    const int lane = threadIdx.x, vpr = t.pitch >> 4, last_row = (t.nvec - 1) / vpr;
-    int row = (int)div_by_rcp((uint32_t)lane, rcp_of((uint32_t)vpr)), c = lane - row * vpr; // vector `lane`; later passes advance by (kd, km)
+    // Addresses are the uniform window base (SGPR pair) + a 32-bit byte offset per lane, advanced incrementally from pass to pass: no 64-bit
+    // vector arithmetic.  Offsets grow with the vector number, so clamping to the last vector's offset keeps the lanes past the end inside
+    // the window (their data is never stored).
+    const int      lane = threadIdx.x, vpr = t.pitch >> 4, nrows = (int)div_by_rcp((uint32_t)t.nvec, rcp_of((uint32_t)vpr));
+    const int      row0 = (int)div_by_rcp((uint32_t)lane, rcp_of((uint32_t)vpr));
+    int            c    = lane - row0 * vpr; // vector `lane` = (row0, c); later passes advance by (kd, km)
+    uint32_t       off  = (uint32_t)__mul24(row0, (int)t.stride) + (uint32_t)c * 16u;
+    const uint32_t last = (uint32_t)__mul24(nrows - 1, (int)t.stride) + (uint32_t)(vpr - 1) * 16u;
+    const uint32_t step = (uint32_t)__mul24(t.kd, (int)t.stride) + (uint32_t)t.km * 16u, wrap = t.stride - (uint32_t)vpr * 16u;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(t.g0);
 #pragma unroll
     for (int j = 0; j < NS; j++)
         if (j * 64 < t.nvec) { // uniform
-            // lanes past the end re-load the last row's vector c (harmless; the load stays unconditional)
-            const int rr = imin(row, last_row);
-            v[S0 + j] = __builtin_bit_cast(V4, *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(t.g0 + (long long)rr * t.stride + c * 16)));
-            row += t.kd; c += t.km;
-            if (c >= vpr) { c -= vpr; row++; }
+            v[S0 + j] = __builtin_bit_cast(V4, *reinterpret_cast<GV4U *>(base + (uint64_t)umin(off, last)));
+            off += step; c += t.km;
+            if (c >= vpr) { c -= vpr; off += wrap; }
         }
 }
 template <int S0, int NS>
@@ -477,7 +523,7 @@ __device__ __forceinline__ void tile_store(const Shared &sh, int nvec, int lds_v
 }
 
 // every position of the tile in the arena; returns the tile's best key (sad << 32 | y << 16 | x), ~0 when no position was evaluated
-__device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t, int lds_off) {
+__device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t, int lds_off PROF_PARAM) {
     St            &st   = sh.st;
     const int      lane = threadIdx.x;
     const uint8_t *src  = src_view(sh, t.level);
@@ -508,6 +554,7 @@ __device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t, int
             const uint32_t cand = m + (uint32_t)seq;
             best = cand < best ? cand : best;
         }
+        PROF(30);
         if ((best >> 12) != 0xFFFFFu) { // decode the visit number: iteration, position in the octet
             const int sq = (int)(best & 0xFFFu), it = lane + (sq >> 3) * kThreads;
             const int y = (int)div_by_rcp((uint32_t)it, ng_rcp), g = it - y * ng;
@@ -530,6 +577,7 @@ __device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t, int
                 if (4 * g + i < t.w) atomicAdd(&st.sadbuf[y * t.w + 4 * g + i], s4[i]);
         }
         wave_sync();
+        PROF(23);
         if (lane < t.w * t.h) {
             const int y = (int)(((float)lane + 0.5f) * __frcp_rn((float)t.w)), x = lane - y * t.w; // exact: w, lane <= 32
             if (!(t.skip_even && !((t.y0 + y) & 1))) { bsad_ = st.sadbuf[lane]; bpos_ = ((uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + x); }
@@ -538,94 +586,87 @@ __device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t, int
     return wave_min_key(bsad_, bpos_);
 }
 
-// Plans the next round and sends its windows on their way into the register slots: either ONE tile of any size that fits the arena (all
-// slots), or up to four small tiles (at most kSmallVec vectors each: slots 2i, 2i + 1) while they fit the arena together.  The tiles'
-// entries go to st.tile[par][] for the later passes.  Returns the number of tiles.
-__device__ __forceinline__ void write_entry(St &st, int par, int i, const TileGeo &t, int lds_vec, int slot0) {
-    if (threadIdx.x == 0) {
-        TileEnt e;
-        e.x0 = (int16_t)t.x0; e.y0 = (int16_t)t.y0; e.w = (int16_t)t.w; e.h = (int16_t)t.h;
-        e.pitch = (uint16_t)t.pitch; e.lds_vec = (uint16_t)lds_vec; e.nvec = (uint16_t)t.nvec; e.slot0 = (uint8_t)slot0; e.req = (uint8_t)t.req;
-        e.bw = (uint8_t)t.bw; e.bh = (uint8_t)t.bh; e.rs = (uint8_t)t.rs;
-        e.flags = (uint8_t)(t.level | (t.skip_even << 2) | (t.narrow << 3) | (t.last << 4));
-        e.pad = 0;
-        st.tile[par][i] = e;
-    }
-}
-__device__ __forceinline__ int plan_and_load(St &st, int nreq, TileCursor &cur, V4 (&v)[kVecPerLane], int par) {
-    TileGeo t = next_tile(st, nreq, cur);
-    if (t.req < 0) return 0;
-    if (t.nvec > kSmallVec) {
-        tile_load<0, kVecPerLane>(t, v);
-        write_entry(st, par, 0, t, 0, 0);
+// The next round of the stage's tile sequence, starting at table entry i (n entries in the table): either ONE tile of any size that fits the
+// arena (all register slots), or up to four small tiles (at most kSmallVec vectors each: slots 2j, 2j + 1) while they fit the arena
+// together.  Sends the round's windows on their way into the register slots; returns the number of tiles.
+__device__ __forceinline__ int load_round(const St &st, int i, int n, V4 (&v)[kVecPerLane], int (&nvo)[4]) {
+    if (i >= n) return 0;
+    // lanes 0 .. 3 look at the sizes of entries i .. i + 3 (one LDS round trip for the whole decision)
+    const int lane = threadIdx.x;
+    const uint32_t nv = (lane < 4 && i + lane < n) ? (uint32_t)st.tile[i + lane].nvec : 0xFFFFu;
+    const int n0 = __builtin_amdgcn_readlane((int)nv, 0), n1 = __builtin_amdgcn_readlane((int)nv, 1), n2 = __builtin_amdgcn_readlane((int)nv, 2),
+              n3 = __builtin_amdgcn_readlane((int)nv, 3);
+    nvo[0] = n0; nvo[1] = n1; nvo[2] = n2; nvo[3] = n3;
+    if (n0 > kSmallVec) {
+        tile_load<0, kVecPerLane>(read_tile(st, i), v);
         return 1;
     }
-    int nt = 0, vecs = 0;
-#define SVT_SMALL_TILE(I)                                                                                              \
-    tile_load<(2 * I < kVecPerLane ? 2 * I : 0), 2>(t, v);                                                             \
-    write_entry(st, par, I, t, vecs, 2 * I);                                                                           \
-    vecs += t.nvec; nt = I + 1;
-#define SVT_NEXT_SMALL()                                                                                               \
-    { const TileCursor save = cur; t = next_tile(st, nreq, cur);                                                       \
-      if (t.req < 0) return nt;                                                                                        \
-      if (t.nvec > kSmallVec || vecs + t.nvec > kWinBytes / 16) { cur = save; return nt; } }
-    SVT_SMALL_TILE(0) SVT_NEXT_SMALL() SVT_SMALL_TILE(1) SVT_NEXT_SMALL() SVT_SMALL_TILE(2) SVT_NEXT_SMALL() SVT_SMALL_TILE(3)
-#undef SVT_SMALL_TILE
-#undef SVT_NEXT_SMALL
+    constexpr int kArenaVec = kWinBytes / 16;
+    int nt = 1;
+    if (n1 <= kSmallVec && n0 + n1 <= kArenaVec) {
+        nt = 2;
+        if (n2 <= kSmallVec && n0 + n1 + n2 <= kArenaVec) {
+            nt = 3;
+            if (n3 <= kSmallVec && n0 + n1 + n2 + n3 <= kArenaVec) nt = 4;
+        }
+    }
+    tile_load<0, 2>(read_tile(st, i), v);
+    if (nt > 1) tile_load<2, 2>(read_tile(st, i + 1), v);
+    if (nt > 2) tile_load<4, 2>(read_tile(st, i + 2), v);
+    if (nt > 3) tile_load<6, 2>(read_tile(st, i + 3), v);
     return nt;
 }
-static_assert(kVecPerLane >= 8 && kRoundTiles >= 4, "four small tiles of two slots each");
+static_assert(kVecPerLane >= 8, "four small tiles of two slots each");
 
 // The wave runs st.req[0 .. nreq) (nreq >= 1) to completion; results in st.req_key[] = (sad << 32 | y << 16 | x), or
 // (0xffffff << 32 | 0xffffffff) when no position was evaluated.  The searches go through the arena in ROUNDS of as many windows as it
-// holds (the eight level-0 windows of a short-distance picture are one round, a level-2 window is a round of its own); while a round is
+// holds (the eight level-0 windows of a short-distance picture are two rounds, a level-2 window is a round of its own); while a round is
 // evaluated out of the arena, the next round's windows are already on their way into registers.
 __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
     St        &st   = sh.st;
     const int  nreq = (int)uni((uint32_t)st.nreq);
-    TileCursor cur  = {0, 0, 0, 0, 0};
     V4         v[kVecPerLane];
-    int        par = 0, nt = plan_and_load(st, nreq, cur, v, 0);
-    u64 key = (0xffffffull << 32) | 0xffffffffull;
-    PROF(17);
-    while (nt) {
-        wave_sync(); // the round's entries
-        { // slots are compile-time: a single big tile sits in all of them, small tile i in slots 2i, 2i + 1
-            const int n0 = (int)uni(st.tile[par][0].nvec);
-            if (n0 > kSmallVec) tile_store<0, kVecPerLane>(sh, n0, 0, v);
-            else {
-                tile_store<0, 2>(sh, n0, 0, v);
-                if (nt > 1) tile_store<2, 2>(sh, (int)uni(st.tile[par][1].nvec), (int)uni(st.tile[par][1].lds_vec), v);
-                if (nt > 2) tile_store<4, 2>(sh, (int)uni(st.tile[par][2].nvec), (int)uni(st.tile[par][2].lds_vec), v);
-                if (nt > 3) tile_store<6, 2>(sh, (int)uni(st.tile[par][3].nvec), (int)uni(st.tile[par][3].lds_vec), v);
+    u64        key = (0xffffffull << 32) | 0xffffffffull;
+    for (int t0 = 0;; t0 += kMaxTiles) { // one pass unless the stage has more than kMaxTiles tiles
+        const int total = plan_tiles(st, nreq, t0), n = imin(total - t0, kMaxTiles);
+        wave_sync(); // the table
+        int nv[4] = {0, 0, 0, 0}, nvn[4] = {0, 0, 0, 0};
+        int i = 0, nt = load_round(st, 0, n, v, nv);
+        PROFS(24);
+        while (nt) {
+            { // slots are compile-time: a single big tile sits in all of them, small tile j in slots 2j, 2j + 1
+                if (nv[0] > kSmallVec) tile_store<0, kVecPerLane>(sh, nv[0], 0, v);
+                else {
+                    tile_store<0, 2>(sh, nv[0], 0, v);
+                    if (nt > 1) tile_store<2, 2>(sh, nv[1], nv[0], v);
+                    if (nt > 2) tile_store<4, 2>(sh, nv[2], nv[0] + nv[1], v);
+                    if (nt > 3) tile_store<6, 2>(sh, nv[3], nv[0] + nv[1] + nv[2], v);
+                }
             }
-        }
-        wave_sync();
-        PROF(18);
-        const int nn = plan_and_load(st, nreq, cur, v, par ^ 1);
-        for (int i = 0; i < nt; i++) {
-            const TileEnt &e = st.tile[par][i];
-            TileGeo t;
-            { // uniform entry -> scalar registers
-                const uint32_t a = uni((uint32_t)(uint16_t)e.x0 | ((uint32_t)(uint16_t)e.y0 << 16)), b = uni((uint32_t)(uint16_t)e.w | ((uint32_t)(uint16_t)e.h << 16));
-                const uint32_t c = uni((uint32_t)e.pitch | ((uint32_t)e.lds_vec << 16)), d = uni((uint32_t)e.req | ((uint32_t)e.bw << 8) | ((uint32_t)e.bh << 16) | ((uint32_t)e.rs << 24));
-                const uint32_t f = uni(e.flags);
-                t.x0 = (int16_t)(a & 0xFFFF); t.y0 = (int16_t)(a >> 16); t.w = (int16_t)(b & 0xFFFF); t.h = (int16_t)(b >> 16);
-                t.pitch = (int)(c & 0xFFFF); t.nvec = 0; t.kd = t.km = 0; t.g0 = nullptr; t.stride = 0;
-                t.req = (int)(d & 0xFF); t.bw = (int)((d >> 8) & 0xFF); t.bh = (int)((d >> 16) & 0xFF); t.rs = (int)(d >> 24);
-                t.level = (int)(f & 3); t.skip_even = (int)((f >> 2) & 1); t.narrow = (int)((f >> 3) & 1); t.last = (int)((f >> 4) & 1);
-                const u64 k = tile_eval(sh, t, (int)(c >> 16) * 16);
+            wave_sync();
+            PROFS(32);
+            const int nn = load_round(st, i + nt, n, v, nvn);
+            PROF(22);
+            int lds_vec = 0;
+            for (int j = 0; j < nt; j++) {
+                const TileGeo t = read_tile(st, i + j);
+                const u64 k = tile_eval(sh, t, lds_vec * 16 PROF_ARG);
                 key = k < key ? k : key;
+                lds_vec += t.nvec;
+                if (t.last) {
+                    if (threadIdx.x == 0) st.req_key[t.req] = key;
+                    key = (0xffffffull << 32) | 0xffffffffull;
+                }
             }
-            if (t.last) {
-                if (threadIdx.x == 0) st.req_key[t.req] = key;
-                key = (0xffffffull << 32) | 0xffffffffull;
-            }
+            wave_sync(); // the arena is free again
+            PROFS(40);
+            i += nt;
+            nt = nn;
+#pragma unroll
+            for (int j = 0; j < 4; j++) nv[j] = nvn[j];
         }
-        wave_sync(); // the arena is free again
-        PROF(21);
-        par ^= 1;
-        nt = nn;
+        if (t0 + kMaxTiles >= total) break;
+        wave_sync(); // the table is rewritten
     }
 }
 
@@ -1464,6 +1505,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 PROF(step == kMain ? 20 : 6 + step);
                 if (step == kC00 && bi == 0 && st.tf_exit) { step = kEnd; continue; } // uniform: LDS value read after the barrier
                 if (step < kProbe) {
+                    PROF_STEP(step);
                     if (st.nreq) run_searches(sh PROF_ARG); // uniform (LDS value read after the barrier)
                 } else {
                     const bool   probe = step == kProbe;
@@ -1471,7 +1513,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     const int    count = probe ? st.nprobe : st.nme;
                     run_me_searches(sh, p, list, count, bsad, bmv, r0n);
                 }
-                PROF(4);
+                PROF(step == kProbe ? 3 : step == kMain ? 4 : 19);
             }
             CTRL_PRIO(SVT_ME_CTRL_PRIO);
             switch (step) { // fold the results in, pick the next stage

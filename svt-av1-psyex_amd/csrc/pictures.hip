@@ -294,17 +294,17 @@ int svt_hip_scratch(SvtHipContext *ctx, SvtHipLane *l, size_t bytes, void **out)
 
 // Diagnostic: per-phase shader-clock sums of the ME kernel (non-zero only in a -DSVT_HIP_ME_PROFILE build), summed over the
 // lanes; clears them.
-extern "C" int svt_hip_me_profile_read(SvtHipContext *ctx, unsigned long long out[24]) {
+extern "C" int svt_hip_me_profile_read(SvtHipContext *ctx, unsigned long long out[48]) {
     if (!ctx || !out) return SVT_HIP_ERR_BAD_PARAM;
-    for (int k = 0; k < 24; k++) out[k] = 0;
+    for (int k = 0; k < 48; k++) out[k] = 0;
     for (int i = 0; i < SVT_HIP_LANES; i++) {
         SvtHipLane &l = ctx->lane[i];
         if (!l.ready) continue;
-        unsigned long long v[24];
+        unsigned long long v[48];
         SVT_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
         SVT_HIP_CHECK(ctx, hipMemcpy(v, reinterpret_cast<char *>(l.queue_head) + 64, sizeof(v), hipMemcpyDeviceToHost));
         SVT_HIP_CHECK(ctx, hipMemset(reinterpret_cast<char *>(l.queue_head) + 64, 0, sizeof(v)));
-        for (int k = 0; k < 24; k++) out[k] += v[k];
+        for (int k = 0; k < 48; k++) out[k] += v[k];
     }
     return SVT_HIP_OK;
 }

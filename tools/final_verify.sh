@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-end verification on the GPU box: full GPU suite, smoke, the bench line, and the rocprofv3 passes profiles/ is built from.
 # Run through gpurun from the repo root; outputs land in gpurun_out/ (then: python3 tools/refresh_profiles.py).
+R=${SVT_ROUND:-r02}
 set -e -o pipefail
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -9,10 +10,12 @@ tail -2 gpurun_out/gpu_tests.log
 timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -1
 timeout -k 10 600 python bench.py > gpurun_out/bench_final.log 2> gpurun_out/bench_final.err || { tail -20 gpurun_out/bench_final.err; exit 1; }
 tail -1 gpurun_out/bench_final.log | cut -c1-400
-rm -rf gpurun_out/r01s gpurun_out/r01f gpurun_out/r01w gpurun_out/pmc7
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r01s -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r01s.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/r01f -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01f.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/r01w -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01w.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES -d gpurun_out/pmc7 -o a --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc7.log 2>&1
-find gpurun_out/r01s gpurun_out/r01f gpurun_out/r01w gpurun_out/pmc7 -name "*.csv" | head -20
+rm -rf gpurun_out/${R}s gpurun_out/${R}f gpurun_out/${R}w gpurun_out/${R}q
+BENCH="bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}s -o bench --output-format csv -- python3 $BENCH > gpurun_out/${R}s.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${R}f -o bench --output-format csv -- python3 $BENCH > gpurun_out/${R}f.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${R}w -o bench --output-format csv -- python3 $BENCH > gpurun_out/${R}w.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD -d gpurun_out/${R}q -o bench --output-format csv -- python3 $BENCH > gpurun_out/${R}q.log 2>&1
+if [ -f tools/_libprof.so ]; then timeout -k 10 300 python tools/me_phase_profile.py > gpurun_out/me_phase.log 2>&1 || tail -5 gpurun_out/me_phase.log; fi
+find gpurun_out/${R}s gpurun_out/${R}f gpurun_out/${R}w gpurun_out/${R}q -name "*.csv" | head -20
 echo verify-done

@@ -1,21 +1,73 @@
-import sys, os
-sys.path.insert(0,'tests'); sys.path.insert(0,'.')
-import numpy as np, ctypes as C
-import me_cases
-from svt_av1_psyex_amd import api, abi
-api.LIB_PATH=os.path.join(os.path.dirname(os.path.abspath(__file__)),'_libprof.so')
-import torch
-from me_cases import MeCase
-ctx=api.Context()
-names=['fetch','setup','-','-','searches-tail','post','pre-zz','pre-prehme','pre-L0','pre-L1','pre-L2','pre-c00','pre-probe','prune','cands','dist','out-tail']
-for dist in (1,):
-    c=MeCase(3840,2160,enc_mode=6,cur=8,refs={(0,0):8-dist,(1,0):8+dist},n_frames=17,seed=11,temporal_layer_index={1:4,8:1}[dist])
-    cur=ctx.upload(c.cur); refs={k:ctx.upload(v) for k,v in c.refs.items()}
-    out=(C.c_ulonglong*24)()
-    ctx.me_picture(c.cfg,c.desc,cur,refs); api.lib().svt_hip_me_profile_read(ctx._h,out)
-    for _ in range(3): ctx.me_picture(c.cfg,c.desc,cur,refs)
-    api.lib().svt_hip_me_profile_read(ctx._h,out)
-    v=np.array(out[:17],dtype=np.float64)/3/2040
-    w=np.array(out[17:24],dtype=np.float64)/3/2040
-    print('   run_searches split: plan-bar',int(w[0]),'stage',int(w[1]),'eval-keys',int(w[2]),'eval-items',int(w[4]),'eval-bar',int(w[5]),'plan',int(w[6]),'pre-main',int(w[3]))
-    print('dist',dist,'cycles per b64 (100MHz ticks?):', {n:int(x) for n,x in zip(names,v)}, 'total',int(v.sum()))
+"""Phase table of svt_hip_me_b64_kernel from the diagnostic build (tools/build_me_profile_lib.sh: -DSVT_HIP_ME_PROFILE, where lane 0 of
+each wave accumulates s_memtime deltas per phase of a block) on bench.py's own ME launch; prints the share of a block's time per phase and
+writes gpurun_out/me_phase_table.txt.   usage (GPU box): python tools/me_phase_profile.py"""
+import ctypes as C
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(HERE, "..", "tests"), os.path.join(HERE, "..")]
+import numpy as np
+
+from svt_av1_psyex_amd import api
+
+api.LIB_PATH = os.path.join(HERE, "_libprof.so")
+
+# index -> phase (PROF(i) in csrc/me_kernel.hip)
+STAGES = ("zero-MV SADs", "pre-HME", "HME level 0", "HME level 1", "HME level 2", "check-00")
+PHASES = [
+    (0, "job fetch (queue atomic)"), (1, "block set-up: source 64x64 / 32x32 / 16x16 views into LDS"), (2, "stage preamble"),
+    (6, "control before zero-MV SADs"), (7, "control before pre-HME"), (8, "control before HME level 0"), (9, "control before HME level 1"),
+    (10, "control before HME level 2"), (11, "control before check-00"), (12, "control before the 8x8-variance probe"), (20, "control before the integer search"),
+] + [(24 + i, f"{n}: plan a round + issue its window loads") for i, n in enumerate(STAGES)] + [(32 + i, f"{n}: window registers -> LDS arena") for i, n in enumerate(STAGES)] + [
+    (40 + i, f"{n}: rest of the evaluation (tile entry -> registers, arg-min across the wave, result)") for i, n in enumerate(STAGES)] + [
+    (22, "all stages: plan the next round + issue its window loads (inside the evaluation phase)"), (30, "all stages: wide tiles, item loop (8 positions x whole block per lane)"),
+    (23, "all stages: narrow tiles, item loop (4 positions x row slice per lane, LDS atomics)"), (19, "searches: tail"), (3, "8x8-variance probe (integer search at one position)"), (4, "integer search (staging, 85-PU SAD pyramid, bests)"),
+    (5, "control after a stage (fold results, centres, early exits)"),
+    (13, "reference pruning"), (14, "candidate lists"), (15, "distortions / variance outputs"), (16, "result rows stored"),
+]
+NSLOT = 48
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402  (the repo's bench.py: its Workload is the launch that is profiled)
+
+ctx = api.Context()
+ext = torch.cuda.ExternalStream(ctx.stream)
+wl = bench.Workload(ctx, 0, 1)
+n_b64 = wl.w64 * wl.h64 * len(bench.PICS)
+out = (C.c_ulonglong * NSLOT)()
+
+
+def launches(n):
+    with torch.cuda.stream(ext):
+        for i in range(n):
+            ctx.me_pictures_async(wl.me_jobs[i % bench.N_SETS][i % 2])
+    ctx.sync()
+
+
+launches(2)
+api.lib().svt_hip_me_profile_read(ctx._h, out)  # reads and clears
+N = 6
+launches(N)
+api.lib().svt_hip_me_profile_read(ctx._h, out)
+col = np.array(out[:NSLOT], dtype=np.float64) / N / n_b64
+tot = col.sum()
+lines = ["svt_hip_me_b64_kernel, diagnostic build -DSVT_HIP_ME_PROFILE (tools/build_me_profile_lib.sh): where a block's wall time goes.  One wave per block; lane 0 accumulates",
+         f"s_memtime deltas per phase; averaged over the {n_b64} blocks of bench.py's launch (16 pictures 3840x2160, preset 6, R = 2, reference distances 8 / 1 / 4 / 2) and {N} launches",
+         "on the three picture sets.  8 waves share a CU, so a phase's share of wall time includes the cycles its wave waited for the other seven to issue.", "",
+         f"{'phase':86s} {'clocks/block':>12s} {'%':>5s}"]
+for i, name in PHASES:
+    lines.append(f"{name:86s} {col[i]:12.0f} {100 * col[i] / tot:5.1f}")
+lines.append(f"{'total clocks per block (s_memtime)':86s} {tot:12.0f}")
+grp = {"control (serial, one lane)": (2, 6, 7, 8, 9, 10, 11, 12, 20, 5, 13), "set-up, outputs, fetch": (0, 1, 14, 15, 16), "probe + integer search": (3, 4)}
+grp.update({n + " (without the item loops)": (24 + i, 32 + i, 40 + i) for i, n in enumerate(STAGES)})
+grp["item loops (22, 30, 23)"] = (22, 30, 23)
+lines.append("")
+for g, idx in grp.items():
+    v = sum(col[i] for i in idx)
+    lines.append(f"{g:86s} {v:12.0f} {100 * v / tot:5.1f}")
+text = "\n".join(lines)
+print(text)
+os.makedirs("gpurun_out", exist_ok=True)
+open("gpurun_out/me_phase_table.txt", "w").write(text + "\n")

@@ -1,13 +1,21 @@
-"""Turns the rocprofv3 outputs merged into gpurun_out/ (r01s = --stats, r01f / r01w = --pmc FETCH_SIZE / WRITE_SIZE, pmc7 = SQ
-counters, bench_final.log) into the committed summaries under profiles/."""
+"""Turns the rocprofv3 outputs merged into gpurun_out/ by tools/final_verify.sh (<R>s = --stats, <R>f / <R>w = --pmc FETCH_SIZE / WRITE_SIZE,
+<R>q = SQ counters, bench_final.log, me_phase_table.txt) into the committed summaries under profiles/."""
 import collections
 import csv
+import glob
 import json
+import os
 import shutil
+import sys
 
-shutil.copy('gpurun_out/r01s/bench_kernel_stats.csv', 'profiles/r01_kernel_stats_bench_steps5.csv')
-out = json.load(open('profiles/r01_hbm_traffic.json'))
-out["kernels"] = {}
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+CMD = "python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras"
+
+
+def one(pattern):
+    f = glob.glob(pattern, recursive=True)
+    assert f, pattern
+    return f[0]
 
 
 def short(k):
@@ -20,9 +28,16 @@ def short(k):
     return None
 
 
-for d, cn in (('r01f', 'FETCH_SIZE'), ('r01w', 'WRITE_SIZE')):
+shutil.copy(one(f'gpurun_out/{R}s/**/*kernel_stats.csv'), f'profiles/{R}_kernel_stats_bench.csv')
+b = json.loads(open('gpurun_out/bench_final.log').read().strip().split('\n')[-1])
+out = {"command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) -- {CMD}",
+       "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB, averaged here over the launches of the run.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE "
+                    "tallies the 128-byte requests of 16-byte-per-lane loads at 64 bytes, so it is doubled for the ME kernel (whose window staging is such loads); the RD kernels' figure "
+                    "matches their known input bytes undoubled (calibrated in round 1: source + prediction planes read once).  Both counters sit on the memory side of L2 and include "
+                    "Infinity-Cache hits.", "kernels": {}}
+for d, cn in ((R + 'f', 'FETCH_SIZE'), (R + 'w', 'WRITE_SIZE')):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f'gpurun_out/{d}/bench_counter_collection.csv')):
+    for r in csv.DictReader(open(one(f'gpurun_out/{d}/**/*counter_collection.csv'))):
         acc[r['Kernel_Name']].append(float(r['Counter_Value']))
     for k, v in acc.items():
         if short(k):
@@ -31,22 +46,39 @@ for d, cn in (('r01f', 'FETCH_SIZE'), ('r01w', 'WRITE_SIZE')):
 for k, v in out["kernels"].items():
     f = 2 if k == 'svt_hip_me_b64_kernel' else 1
     v["hbm_bytes_per_launch"] = int((f * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024)
-json.dump(out, open('profiles/r01_hbm_traffic.json', 'w'), indent=1)
-b = json.loads(open('gpurun_out/bench_final.log').read().strip().split('\n')[-1])
-json.dump(b, open('profiles/r01_bench_final.json', 'w'), indent=1)
+alg = {"svt_hip_me_b64_kernel": b["roofline"]["algorithmic_bytes_per_launch"], **{k: v["algorithmic_bytes_per_launch"] for k, v in b["rd_roofline"].items()}}
+for k, v in out["kernels"].items():
+    kk = k.replace("(TxSize)", "").replace(", 10>", ", 10>")
+    for a, by in alg.items():
+        if a.split('<')[0] == k.split('<')[0] and (a == k or a.split('<')[-1].split(',')[0] in k or k == 'svt_hip_me_b64_kernel'):
+            v["algorithmic_bytes_per_launch"] = by
+            v["traffic_over_algorithmic"] = round(v["hbm_bytes_per_launch"] / by, 2)
+            break
+json.dump(out, open(f'profiles/{R}_hbm_traffic.json', 'w'), indent=1)
+json.dump(b, open(f'profiles/{R}_bench_final.json', 'w'), indent=1)
 acc = collections.defaultdict(list)
-for r in csv.DictReader(open('gpurun_out/pmc7/a_counter_collection.csv')):
+for r in csv.DictReader(open(one(f'gpurun_out/{R}q/**/*counter_collection.csv'))):
     if short(r['Kernel_Name']) and 'fullpel' not in r['Kernel_Name']:
         acc[(short(r['Kernel_Name']), r['Counter_Name'])].append(float(r['Counter_Value']))
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
-busy = {k: 4 * avg[(k, 'SQ_ACTIVE_INST_VALU')] / 1024 / (avg[(k, 'SQ_BUSY_CYCLES')] / 32) for k in {kk[0] for kk in avg}}
-with open('profiles/r01_sq_counters.txt', 'w') as f:
-    f.write("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
-    f.write("average per launch (one launch = the 16 pictures of a step); *_CYCLES / ACTIVE / WAIT counters are in quad-cycles per wave (x4 = clocks); SQ_BUSY_CYCLES summed over 32 shader engines\n")
-    f.write("derived: VALU busy per SIMD = 4*SQ_ACTIVE_INST_VALU/1024 / (SQ_BUSY_CYCLES/32): " + ", ".join(f"{k} {100 * v:.0f} %" for k, v in sorted(busy.items())) + "\n\n")
+kern = sorted({kk[0] for kk in avg})
+busy = {k: 4 * avg[(k, 'SQ_ACTIVE_INST_VALU')] / 1024 / (avg[(k, 'SQ_BUSY_CYCLES')] / 32) for k in kern}
+wait = {k: avg[(k, 'SQ_WAIT_ANY')] / avg[(k, 'SQ_WAVE_CYCLES')] for k in kern}
+with open(f'profiles/{R}_sq_counters.txt', 'w') as f:
+    f.write(f"rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD -- {CMD}\n")
+    f.write("average per launch (one launch = the 16 pictures of a step = 32,640 blocks of 64x64 for the ME kernel); *_CYCLES / ACTIVE / WAIT counters are in quad-cycles per wave (x4 = clocks); SQ_BUSY_CYCLES summed over 32 shader engines\n")
+    f.write("derived: VALU busy per SIMD = 4*SQ_ACTIVE_INST_VALU/1024 / (SQ_BUSY_CYCLES/32): " + ", ".join(f"{k} {100 * v:.0f} %" for k, v in sorted(busy.items())) + "\n")
+    f.write("derived: share of wave-cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES): " + ", ".join(f"{k} {100 * v:.0f} %" for k, v in sorted(wait.items())) + "\n")
+    me = 'svt_hip_me_b64_kernel'
+    if (me, 'SQ_INSTS_VALU') in avg:
+        nb = 32640.0
+        f.write("derived: ME kernel wave-instructions per 64x64 block: " + ", ".join(f"{c[9:]} {avg[(me, c)] / nb:.0f}" for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD')) + "\n")
+    f.write("\n")
     for k in sorted(avg):
         f.write(f"{k[0]:28s} {k[1]:22s} {avg[k]:.4g}\n")
-print(open('profiles/r01_kernel_stats_bench_steps5.csv').read()[:720])
-print({k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items()})
-print(b["value"], b["kernel_ms"], b["roofline"], b["cpu_baseline"])
+if os.path.exists('gpurun_out/me_phase_table.txt'):
+    shutil.copy('gpurun_out/me_phase_table.txt', f'profiles/{R}_me_phase_table.txt')
+print(open(f'profiles/{R}_kernel_stats_bench.csv').read()[:900])
+print({k: (v["hbm_bytes_per_launch"], v.get("traffic_over_algorithmic")) for k, v in out["kernels"].items()})
+print(b["value"], b["kernel_ms"], b["roofline"], b.get("cpu_baseline"))
 print({k: round(v, 2) for k, v in busy.items()})
