@@ -28,12 +28,14 @@
 // Diagnostic build only (-DSVT_HIP_ME_PROFILE): lane 0 accumulates shader-clock deltas per phase (private array) and adds
 // them to queue_head[16 + 2*i] (u64) when the wave retires.  Never defined in the shipped library.
 #ifdef SVT_HIP_ME_PROFILE
-struct Prof { unsigned long long acc[48], last; int step; };
-#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < 48; i_++) prof_.acc[i_] = 0; prof_.last = clock64(); prof_.step = 0; Prof *prof = &prof_
+// the sums live behind the wave's LDS slice (48 x u32, added with ds_add_u32: a profiling point costs one s_memtime and one LDS atomic)
+struct Prof { uint32_t *acc; unsigned long long last; int step; };
+#define SVT_HIP_ME_PROFILE_LDS (48 * 4)
+#define PROF_DECL Prof prof_; prof_.acc = reinterpret_cast<uint32_t *>(g_lds + lay.total); if (threadIdx.x < 48) prof_.acc[threadIdx.x] = 0; prof_.last = __builtin_readcyclecounter(); prof_.step = 0; Prof *prof = &prof_
 #define PROF_STEP(s) (prof->step = (s))
 #define PROFS(i) PROF((i) + prof->step) /* per-stage slots: 24.. plan, 32.. staging, 40.. evaluation */
-#define PROF(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); prof->acc[i] += t_ - prof->last; prof->last = t_; } } while (0)
-#define PROF_FLUSH(ptr) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 48; i_++) atomicAdd((unsigned long long *)(ptr) + i_, prof->acc[i_]); } while (0)
+#define PROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&prof->acc[i], (uint32_t)(t_ - prof->last)); prof->last = t_; } while (0)
+#define PROF_FLUSH(ptr) do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); if (threadIdx.x < 48) atomicAdd((unsigned long long *)(ptr) + threadIdx.x, (unsigned long long)prof->acc[threadIdx.x]); } while (0)
 #define PROF_PARAM , Prof *prof
 #define PROF_ARG , prof
 #else
@@ -42,6 +44,7 @@ struct Prof { unsigned long long acc[48], last; int step; };
 #define PROFS(i) do { } while (0)
 #define PROF_STEP(s) do { } while (0)
 #define PROF_FLUSH(ptr) do { } while (0)
+#define SVT_HIP_ME_PROFILE_LDS 0
 #define PROF_PARAM
 #define PROF_ARG
 #endif
@@ -262,8 +265,16 @@ __device__ __forceinline__ void quad_sad_rows(const uint8_t *src, int src_pitch,
             const uint32_t *s = reinterpret_cast<const uint32_t *>(src + r * srs * src_pitch);
             const uint32_t *w = reinterpret_cast<const uint32_t *>(wrow0 + r * rs * pitch);
             uint32_t sv[NDW], wv[NDW + 1];
+            if constexpr (NDW % 4 == 0) { // source rows are 16-byte aligned in LDS: whole-vector reads
 #pragma unroll
-            for (int j = 0; j < NDW; j++) sv[j] = s[j];
+                for (int j = 0; j < NDW; j += 4) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(s + j);
+                    sv[j] = q.x; sv[j + 1] = q.y; sv[j + 2] = q.z; sv[j + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NDW; j++) sv[j] = s[j];
+            }
 #pragma unroll
             for (int j = 0; j <= NDW; j++) wv[j] = w[j];
 #pragma unroll
@@ -347,8 +358,16 @@ __device__ __forceinline__ void oct_sad_rows(const uint8_t *src, int src_pitch, 
 #pragma unroll
                     for (int j = 0; j < CH; j++) sv[j] = s[c0 + j];
                 }
+                if constexpr (CH % 2 == 0) { // octets start on 8-byte boundaries of the arena: 8-byte window reads
 #pragma unroll
-                for (int j = 0; j < CH + 2; j++) wv[j] = w[c0 + j];
+                    for (int j = 0; j < CH + 2; j += 2) {
+                        const uint2 q = *reinterpret_cast<const uint2 *>(w + c0 + j);
+                        wv[j] = q.x; wv[j + 1] = q.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CH + 2; j++) wv[j] = w[c0 + j];
+                }
 #pragma unroll
                 for (int j = 0; j < CH; j++) {
                     acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 1] << 32) | wv[j], sv[j], acc0);
@@ -1769,7 +1788,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
 #undef BEST_SAD
 #undef BEST_MV
 
-size_t svt_hip_me_kernel_lds_bytes(void) { return lds_layout(SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS, 0).total; }
+size_t svt_hip_me_kernel_lds_bytes(void) { return lds_layout(SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS, 0).total + SVT_HIP_ME_PROFILE_LDS; }
 
 #include "svt_hip_internal.h"
 
@@ -1804,7 +1823,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     }
     // persistent waves: as many per CU as the LDS slices (the window arena + the launch's best_sad / best_mv rows) and the register
     // budget of the launch bounds keep resident
-    const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift).total + 127) & ~(size_t)127;
+    const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift).total + SVT_HIP_ME_PROFILE_LDS + 127) & ~(size_t)127;
     uint32_t per_cu = (uint32_t)((160u * 1024u) / lds);
     if (per_cu > 4u * SVT_HIP_ME_WAVES_PER_SIMD) per_cu = 4u * SVT_HIP_ME_WAVES_PER_SIMD;
     if (ctx->me_waves_per_cu && per_cu > ctx->me_waves_per_cu) per_cu = ctx->me_waves_per_cu; // the caller leaves room for kernels of another stream
