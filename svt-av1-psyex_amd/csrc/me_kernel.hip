@@ -55,10 +55,6 @@ constexpr int kThreads  = 64;    // one wave per block
 constexpr int kMaxReq   = 32;    // searches per stage (4 HME regions x 8 refs)
 constexpr int kWinBytes = SVT_HIP_ME_WIN_BYTES; // LDS window arena of a wave
 constexpr int kSrc64Pitch = 80, kSrc32Pitch = 48, kSrc16Pitch = 16; // LDS row pitches of the source views: block rows 2 apart land on different banks
-#ifndef SVT_ME_ROWS_PER_SLICE
-#define SVT_ME_ROWS_PER_SLICE 2
-#endif
-constexpr int kRowsPerSlice = SVT_ME_ROWS_PER_SLICE; // block rows one item of a row-split (narrow) search accumulates before its LDS atomics
 constexpr int kNarrowMaxPos = 32; // searches with at most this many positions are split by block row instead
 
 // z_to_raster, motion_estimation.c:2520-2531: n_idx (quad-tree order) -> raster-within-depth PU index
@@ -580,20 +576,24 @@ __device__ __forceinline__ u64 tile_eval(const Shared &sh, const TileGeo &t, int
             bsad_ = best >> 12;
             bpos_ = ((uint32_t)(t.y0 + y) << 16) | (uint32_t)(t.x0 + 8 * g + (sq & 7));
         }
-    } else { // few positions: lane <-> 4 positions x kRowsPerSlice block rows, summed per position in LDS
+    } else { // few positions: lane <-> 8 positions x a slice of the block rows (as many slices as keep the wave's lanes busy), summed per position in LDS
         if (lane < kNarrowMaxPos) st.sadbuf[lane] = 0;
         wave_sync();
-        const int   ng = (t.w + 3) >> 2, slices = (t.bh + kRowsPerSlice - 1) / kRowsPerSlice, nitems = ng * t.h * slices;
+        const int ng = (t.w + 7) >> 3, per = ng * t.h;
+        int       slices = imin(t.bh, imax(1, (int)uni(div_by_rcp(64u, rcp_of((uint32_t)per)))));
+        const int rows_per = (int)uni(div_by_rcp((uint32_t)(t.bh + slices - 1), rcp_of((uint32_t)slices)));
+        slices = (int)uni(div_by_rcp((uint32_t)(t.bh + rows_per - 1), rcp_of((uint32_t)rows_per)));
+        const int   nitems = per * slices;
         const float ng_rcp = rcp_of((uint32_t)ng), h_rcp = rcp_of((uint32_t)t.h);
         for (int it = lane; it < nitems; it += kThreads) {
             const int q = (int)div_by_rcp((uint32_t)it, ng_rcp), g = it - q * ng;
             const int slice = (int)div_by_rcp((uint32_t)q, h_rcp), y = q - slice * t.h;
             if (t.skip_even && !((t.y0 + y) & 1)) continue;
-            uint32_t  s4[4];
-            quad_sad(src, sp, srs, win + y * t.pitch + 4 * g, t.pitch, t.rs, t.bw, slice * kRowsPerSlice, imin(slice * kRowsPerSlice + kRowsPerSlice, t.bh), s4);
+            uint32_t s8[8];
+            oct_sad(src, sp, srs, win + y * t.pitch + 8 * g, t.pitch, t.rs, t.bw, slice * rows_per, imin(slice * rows_per + rows_per, t.bh), s8);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (4 * g + i < t.w) atomicAdd(&st.sadbuf[y * t.w + 4 * g + i], s4[i]);
+            for (int i = 0; i < 8; i++)
+                if (8 * g + i < t.w) atomicAdd(&st.sadbuf[y * t.w + 8 * g + i], s8[i]);
         }
         wave_sync();
         PROF(23);
