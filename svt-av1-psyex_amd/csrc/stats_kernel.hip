@@ -126,6 +126,76 @@ __device__ void hadamard_tile(HadLds &L, int n, int lane) {
     }
 }
 
+// ---- hadamard_path's 16x16 / 32x32 tiles on the matrix cores --------------------------------------------------------------
+// The 8x8 cores of a 16x16 block are Y = H16 * (X * H16) with H16 = diag(H8, H8): two v_mfma_f32_16x16x16_f16.  Exact: 9-bit residuals and
+// +-1 weights are f16 values, |X * H16| <= 8 * 255 = 2040 < 2048 is still an f16 integer, the f32 sums stay below 2^15; and the first
+// product's C layout (lane holds rows k0 .. k0 + 3 of column r) is the second product's B layout.  The reference's 8-point transform is
+// the same set of Walsh rows in another order without sign changes (every row starts with +1), so combining the four 8x8 blocks of a 16x16
+// element by element (picture_operators_c.c:270-297: (a0 +- a1) >> 1 ...) and the four 16x16 blocks of a 32x32 (:299-326, >> 2) gives the
+// reference's coefficients in a permuted order -- and SATD is a sum.  (tools/ubench/hadamard_mfma.hip measures the 8x8 core alone.)
+typedef _Float16 had_half4 __attribute__((ext_vector_type(4)));
+typedef float    had_float4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ had_half4 had16_weights(int lane) { // H16[r][k0 + j] = H16[k0 + j][r]
+    const int r = lane & 15, k0 = 4 * (lane >> 4);
+    had_half4 h;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = k0 + j;
+        h[j] = ((k >> 3) != (r >> 3)) ? (_Float16)0 : ((__builtin_popcount((k & 7) & (r & 7)) & 1) ? (_Float16)-1 : (_Float16)1);
+    }
+    return h;
+}
+
+// the 16x16 block of L.res at (16 by, 16 bx): this lane's four 16x16-Hadamard coefficients (svt_aom_hadamard_16x16_c arithmetic)
+__device__ __forceinline__ void had16_mfma(const HadLds &L, int by, int bx, int lane, had_half4 h, int32_t out[4]) {
+    const int      r = lane & 15, k0 = 4 * (lane >> 4);
+    const int16_t *x = L.res + (16 * by + r) * kResPitch + 16 * bx + k0;
+    had_half4 a;
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = (_Float16)x[j];
+    had_float4 t = {0, 0, 0, 0};
+    t = __builtin_amdgcn_mfma_f32_16x16x16f16(a, h, t, 0, 0, 0); // T = X * H16: lane holds T[k0 + j][r]
+    had_half4 tb;
+#pragma unroll
+    for (int j = 0; j < 4; j++) tb[j] = (_Float16)t[j];
+    had_float4 y = {0, 0, 0, 0};
+    y = __builtin_amdgcn_mfma_f32_16x16x16f16(h, tb, y, 0, 0, 0); // Y = H16 * T: lane holds Y[k0 + j][r], 8x8 block (k0 / 8, r / 8)
+    const bool right = (lane & 8) != 0, bottom = (lane & 32) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int v = (int)y[j], p8 = __shfl_xor(v, 8, 64), p32 = __shfl_xor(v, 32, 64), p40 = __shfl_xor(v, 40, 64);
+        // the element's four 8x8 blocks in raster order
+        const int l0 = right ? p8 : v, r0 = right ? v : p8;       // this lane's row of blocks: left, right
+        const int l1 = right ? p40 : p32, r1 = right ? p32 : p40; // the other row of blocks
+        const int a0 = bottom ? l1 : l0, a1 = bottom ? r1 : r0, a2 = bottom ? l0 : l1, a3 = bottom ? r0 : r1;
+        const int b0 = (a0 + a1) >> 1, b1 = (a0 - a1) >> 1, b2 = (a2 + a3) >> 1, b3 = (a2 - a3) >> 1;
+        out[j] = right ? (bottom ? b1 - b3 : b1 + b3) : (bottom ? b0 - b2 : b0 + b2);
+    }
+}
+
+// sum of the absolute Hadamard coefficients of the n x n residual tile in L.res, n = 16 or 32 (this lane's share)
+__device__ __forceinline__ uint32_t hadamard_satd_mfma(const HadLds &L, int n, int lane) {
+    const had_half4 h = had16_weights(lane);
+    uint32_t s = 0;
+    if (n == 16) {
+        int32_t o[4];
+        had16_mfma(L, 0, 0, lane, h, o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) s += (uint32_t)(o[j] < 0 ? -o[j] : o[j]);
+        return s;
+    }
+    int32_t o0[4], o1[4], o2[4], o3[4];
+    had16_mfma(L, 0, 0, lane, h, o0); had16_mfma(L, 0, 1, lane, h, o1); had16_mfma(L, 1, 0, lane, h, o2); had16_mfma(L, 1, 1, lane, h, o3);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int b0 = (o0[j] + o1[j]) >> 2, b1 = (o0[j] - o1[j]) >> 2, b2 = (o2[j] + o3[j]) >> 2, b3 = (o2[j] - o3[j]) >> 2;
+        const int c0 = b0 + b2, c1 = b1 + b3, c2 = b0 - b2, c3 = b1 - b3;
+        s += (uint32_t)(c0 < 0 ? -c0 : c0) + (uint32_t)(c1 < 0 ? -c1 : c1) + (uint32_t)(c2 < 0 ? -c2 : c2) + (uint32_t)(c3 < 0 ? -c3 : c3);
+    }
+    return s;
+}
+
 // A block of a plane, optionally seen through the 2-tap bilinear interpolation of svt_aom_sub_pixel_variance{W}x{H}_c
 // (C_DEFAULT/variance.c:28-75,308-318; taps {128 - 16k, 16k}, filter.h:39-48): horizontal pass into 16 bit, vertical pass
 // back to the pixel range, each with a rounding shift by FILTER_BITS = 7.  Evaluated on the fly (4 cached reads per
@@ -304,8 +374,11 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
                         L.res[r * kResPitch + c] = (int16_t)((int16_t)src.at(ty + r, tx + c) - (int16_t)ref.at(ty + r, tx + c));
                     }
                     __syncthreads();
-                    hadamard_tile(L, n, lane);
-                    for (int i = lane; i < n * n; i += 64) { const int32_t v = L.c[i]; satd += (uint32_t)(v < 0 ? -v : v); }
+                    if (n >= 16) satd += hadamard_satd_mfma(L, n, lane); // uniform
+                    else {
+                        hadamard_tile(L, n, lane);
+                        for (int i = lane; i < n * n; i += 64) { const int32_t v = L.c[i]; satd += (uint32_t)(v < 0 ? -v : v); }
+                    }
                     __syncthreads();
                 }
         }

@@ -76,6 +76,22 @@ with open(f'profiles/{R}_sq_counters.txt', 'w') as f:
     f.write("\n")
     for k in sorted(avg):
         f.write(f"{k[0]:28s} {k[1]:22s} {avg[k]:.4g}\n")
+# MFMA evidence: the block-statistics launches of bench.py's `other_kernels` leg (hadamard_path's 16x16 / 32x32 tiles on the matrix cores)
+try:
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(one(f'gpurun_out/{R}m/**/*counter_collection.csv'))):
+        if 'block_stats_kernel' in r['Kernel_Name']:
+            acc[(r['Kernel_Name'].split('(')[0][-60:], r['Counter_Name'])].append(float(r['Counter_Value']))
+    with open(f'profiles/{R}_mfma_counters.txt', 'w') as f:
+        f.write("rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline\n")
+        f.write("block_stats_kernel launches (average per launch); the 8-bit instantiation with `satd` requested runs hadamard_path's 16x16 / 32x32 tiles as v_mfma_f32_16x16x16_f16 pairs\n\n")
+        for k in sorted(acc):
+            f.write(f"{k[0]:62s} {k[1]:28s} {sum(acc[k]) / len(acc[k]):.4g}  ({len(acc[k])} launches)\n")
+        if os.path.exists('gpurun_out/hadamard_mfma.txt'):
+            f.write("\ntools/ubench/hadamard_mfma (the 8x8 core + SATD alone, int16 residual blocks, VALU butterflies vs two f16 MFMAs per four blocks):\n")
+            f.write(open('gpurun_out/hadamard_mfma.txt').read())
+except AssertionError:
+    pass
 if os.path.exists('gpurun_out/me_phase_table.txt'):
     shutil.copy('gpurun_out/me_phase_table.txt', f'profiles/{R}_me_phase_table.txt')
 print(open(f'profiles/{R}_kernel_stats_bench.csv').read()[:900])
