@@ -12,10 +12,12 @@
 //   svt_aom_hadamard_{4x4,8x8,16x16,32x32}_c, svt_aom_satd_c        C_DEFAULT/picture_operators_c.c:176-326, Codec/common_dsp_rtcd.c:70-77
 //   hadamard_path_c                                                 Codec/enc_mode_config.c:2151-2217
 //
-// One wave64 per job.  Pixel statistics are lane-strided sums reduced across the wave; the Hadamard works on
-// <= 32x32 tiles staged in LDS with the reference's exact 16-bit / 32-bit intermediate widths and truncating shifts
-// (which is why this is butterfly code on the VALU and not an MFMA contraction: the shifts between the 8 / 16 / 32
-// stages are not linear, and 9-bit residuals do not fit the 8-bit integer MFMA operands).
+// One wave64 works through kJobsPerWave consecutive jobs (a wave per 8x8 block is launch-bound: 43k single-job waves of a 1080p picture
+// took as long as 11k four-job waves).  Pixel statistics: a lane takes 4 neighbouring samples at a time (one 4- or 8-byte load per plane;
+// 8-bit: v_sad_u8 and three v_dot4_u32_u8 give SAD, sum and sum of squares; 10-bit: packed 16-bit differences, v_sad_u16, v_dot2_i32_i16),
+// lane sums reduced across the wave by DPP.  hadamard_path: <= 32x32 tiles staged in LDS; 16x16 / 32x32 tiles run their 8x8 cores on the matrix
+// cores (exact in f16 operands) and the reference's truncating 16 / 32 combines on the VALU, 4x4 / 8x8 tiles are VALU butterflies with the
+// reference's 16-bit intermediates.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdint.h>
@@ -36,6 +38,18 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// 32-bit sum over the wave by DPP (no LDS crossbar traffic): the total lands in lane 63, returned to every lane as a scalar
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+#define SVT_SUM_DPP(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, true);
+    SVT_SUM_DPP(0x111, 0xF) // row_shr:1
+    SVT_SUM_DPP(0x112, 0xF) // row_shr:2
+    SVT_SUM_DPP(0x114, 0xF) // row_shr:4
+    SVT_SUM_DPP(0x118, 0xF) // row_shr:8: lane 15 of every row holds the row's sum
+#undef SVT_SUM_DPP
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // ---- Hadamard building blocks (same operation order and intermediate widths as the reference) -----------------
@@ -147,8 +161,8 @@ __device__ __forceinline__ had_half4 had16_weights(int lane) { // H16[r][k0 + j]
     return h;
 }
 
-// the 16x16 block of L.res at (16 by, 16 bx): this lane's four 16x16-Hadamard coefficients (svt_aom_hadamard_16x16_c arithmetic)
-__device__ __forceinline__ void had16_mfma(const HadLds &L, int by, int bx, int lane, had_half4 h, int32_t out[4]) {
+// the four 8x8 Hadamards of the 16x16 block of L.res at (16 by, 16 bx): this lane's coefficients Y[k0 + j][r] of 8x8 block (k0 / 8, r / 8)
+__device__ __forceinline__ void had8x4_mfma(const HadLds &L, int by, int bx, int lane, had_half4 h, int32_t out[4]) {
     const int      r = lane & 15, k0 = 4 * (lane >> 4);
     const int16_t *x = L.res + (16 * by + r) * kResPitch + 16 * bx + k0;
     had_half4 a;
@@ -161,10 +175,18 @@ __device__ __forceinline__ void had16_mfma(const HadLds &L, int by, int bx, int 
     for (int j = 0; j < 4; j++) tb[j] = (_Float16)t[j];
     had_float4 y = {0, 0, 0, 0};
     y = __builtin_amdgcn_mfma_f32_16x16x16f16(h, tb, y, 0, 0, 0); // Y = H16 * T: lane holds Y[k0 + j][r], 8x8 block (k0 / 8, r / 8)
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[j] = (int)y[j];
+}
+
+// the 16x16 block of L.res at (16 by, 16 bx): this lane's four 16x16-Hadamard coefficients (svt_aom_hadamard_16x16_c arithmetic)
+__device__ __forceinline__ void had16_mfma(const HadLds &L, int by, int bx, int lane, had_half4 h, int32_t out[4]) {
+    int32_t y[4];
+    had8x4_mfma(L, by, bx, lane, h, y);
     const bool right = (lane & 8) != 0, bottom = (lane & 32) != 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int v = (int)y[j], p8 = __shfl_xor(v, 8, 64), p32 = __shfl_xor(v, 32, 64), p40 = __shfl_xor(v, 40, 64);
+        const int v = y[j], p8 = __shfl_xor(v, 8, 64), p32 = __shfl_xor(v, 32, 64), p40 = __shfl_xor(v, 40, 64);
         // the element's four 8x8 blocks in raster order
         const int l0 = right ? p8 : v, r0 = right ? v : p8;       // this lane's row of blocks: left, right
         const int l1 = right ? p40 : p32, r1 = right ? p32 : p40; // the other row of blocks
@@ -322,57 +344,112 @@ struct StatsParams {
     SvtHipBlockStatsDesc d;
 };
 
-template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel(const StatsParams p) {
-    __shared__ HadLds L;
-    const int      lane = threadIdx.x;
-    const uint32_t job  = blockIdx.x;
+constexpr int kJobsPerWave = 4;
+typedef uint32_t U32U __attribute__((aligned(1)));
+typedef uint32_t U64U __attribute__((ext_vector_type(2), aligned(2)));
+typedef short    short2v __attribute__((ext_vector_type(2)));
+
+// SAD, sum and sum of squares of the differences of 4 neighbouring samples, added to the lane's running sums
+__device__ __forceinline__ void quad_stats(const uint8_t *s, const uint8_t *r, uint32_t &sad, int32_t &sum, uint32_t &sq) {
+    const uint32_t a = *reinterpret_cast<const U32U *>(s), b = *reinterpret_cast<const U32U *>(r);
+    sad = __builtin_amdgcn_sad_u8(a, b, sad);
+    sum += (int32_t)__builtin_amdgcn_sad_u8(a, 0u, 0u) - (int32_t)__builtin_amdgcn_sad_u8(b, 0u, 0u);
+    // sum (a - b)^2 = a.a + b.b - 2 a.b on the packed-byte dot product
+    sq += __builtin_amdgcn_udot4(a, a, __builtin_amdgcn_udot4(b, b, 0u, false), false) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
+}
+__device__ __forceinline__ void quad_stats(const uint16_t *s, const uint16_t *r, uint32_t &sad, int32_t &sum, uint32_t &sq) {
+    const U64U a = *reinterpret_cast<const U64U *>(s), b = *reinterpret_cast<const U64U *>(r);
+    const short2v one = {1, 1};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t x = k ? a.y : a.x, y = k ? b.y : b.x;
+        const short2v  d = __builtin_bit_cast(short2v, x) - __builtin_bit_cast(short2v, y); // 10-bit samples: no wrap
+        sad = __builtin_amdgcn_sad_u16(x, y, sad);
+        sum = __builtin_amdgcn_sdot2(d, one, sum, false);
+        sq  = (uint32_t)__builtin_amdgcn_sdot2(d, d, (int)sq, false);
+    }
+}
+
+// residuals of 4 neighbouring samples -> 4 x int16 in the LDS tile
+__device__ __forceinline__ void quad_residual(const uint8_t *s, const uint8_t *r, int16_t *dst) {
+    const uint32_t a = *reinterpret_cast<const U32U *>(s), b = *reinterpret_cast<const U32U *>(r);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = (int16_t)((int)((a >> (8 * k)) & 0xFF) - (int)((b >> (8 * k)) & 0xFF));
+}
+__device__ __forceinline__ void quad_residual(const uint16_t *s, const uint16_t *r, int16_t *dst) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = (int16_t)((int16_t)s[k] - (int16_t)r[k]);
+}
+
+// a non-negative 64-bit value by a block's sample count (a power of two for every AV1 block shape)
+__device__ __forceinline__ i64 div_by_area(i64 v, int area) { return (area & (area - 1)) ? v / area : v >> (31 - __builtin_clz(area)); }
+
+// the per-block outputs that follow from the SAD, the sum and the sum of squares of the differences (one lane)
+__device__ __forceinline__ void write_pixel_outputs(const StatsParams &p, uint32_t job, int w, int h, uint32_t sad, int32_t sum, u64 sse) {
+    const uint32_t sq32 = (uint32_t)sse; // the reference's 32-bit accumulator (variance.c) wraps the same way
+    if (p.d.sad) p.d.sad[job] = sad;
+    if (p.d.sse) p.d.sse[job] = sse;
+    if (p.d.var_sse) p.d.var_sse[job] = sq32;
+    if (p.d.variance) p.d.variance[job] = sq32 - (uint32_t)div_by_area((i64)sum * sum, w * h);
+    if (p.d.variance10 || p.d.var_sse10) { // highbd_10_variance (svt_psnr.c:160-177): rounding shifts, then the clamped variance
+        const uint32_t sse10 = (uint32_t)((sse + 8) >> 4);
+        const i64      sum10 = ((i64)sum + 2) >> 2;
+        const i64      var   = (i64)sse10 - div_by_area(sum10 * sum10, w * h);
+        if (p.d.var_sse10) p.d.var_sse10[job] = sse10;
+        if (p.d.variance10) p.d.variance10[job] = var >= 0 ? (uint32_t)var : 0u;
+    }
+    // svt_spatial_full_distortion_kernel_facade (picture_operators_c.c:115-174)
+    if (p.d.facade_dist)
+        p.d.facade_dist[job] = (u64)svt_hip_spy_rd_bias_inline((i64)sse, (uint32_t)w, (uint32_t)h, p.d.pred_mode[job], p.d.compound_type[job],
+                                                               p.d.temporal_layer_index, p.d.psy_rd, p.d.spy_rd);
+}
+
+template <typename Pix>
+__device__ __forceinline__ void block_stats_job(const StatsParams &p, HadLds &L, const uint32_t job, const int lane, const bool with_satd, uint32_t &o_sad, int32_t &o_sum, u64 &o_sse) {
     const SvtHipBlockJob jb = p.d.jobs[job];
     const int w = jb.width, h = jb.height;
     const View<Pix> src = {static_cast<const Pix *>(p.d.src) + jb.src_offset, p.d.src_stride, 16 * (jb.subpel_x & 7), 16 * (jb.subpel_y & 7)};
     const View<Pix> ref = {static_cast<const Pix *>(p.d.ref) + jb.ref_offset, p.d.ref_stride, 0, 0};
-    uint32_t sad = 0, sq32 = 0;
+    uint32_t sad = 0, sq = 0; // a lane sees at most 128 * 128 / 64 samples: its sum of squares stays below 2^32
     int32_t  sum = 0;
-    u64      sse = 0;
-    const float rw = __builtin_amdgcn_rcpf((float)w);
-    for (int i = lane; i < w * h; i += 64) {
-        const int r = (int)(((float)i + 0.5f) * rw), c = i - r * w; // exact for i < 2^21
-        const int d = src.at(r, c) - ref.at(r, c);
-        sad += (uint32_t)(d < 0 ? -d : d);
-        sum += d;
-        sq32 += (uint32_t)(d * d);
-        sse += (u64)((i64)d * d);
-    }
-    sad  = wave_sum(sad);
-    sum  = wave_sum(sum);
-    sq32 = wave_sum(sq32);
-    sse  = wave_sum(sse);
-    if (lane == 0) {
-        if (p.d.sad) p.d.sad[job] = sad;
-        if (p.d.sse) p.d.sse[job] = sse;
-        if (p.d.var_sse) p.d.var_sse[job] = sq32;
-        if (p.d.variance) p.d.variance[job] = sq32 - (uint32_t)(((i64)sum * sum) / (w * h));
-        if (p.d.variance10 || p.d.var_sse10) { // highbd_10_variance (svt_psnr.c:160-177): rounding shifts, then the clamped variance
-            const uint32_t sse10 = (uint32_t)((sse + 8) >> 4);
-            const i64      sum10 = ((i64)sum + 2) >> 2;
-            const i64      var   = (i64)sse10 - (sum10 * sum10) / (w * h);
-            if (p.d.var_sse10) p.d.var_sse10[job] = sse10;
-            if (p.d.variance10) p.d.variance10[job] = var >= 0 ? (uint32_t)var : 0u;
+    if (!(src.fx1 | src.fy1) && !(w & 3)) { // uniform: plain blocks, 4 samples per lane and step
+        const int   wq = w >> 2;
+        const float rq = __builtin_amdgcn_rcpf((float)wq);
+        for (int i = lane; i < wq * h; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * rq), c = 4 * (i - r * wq);
+            quad_stats(src.p + (size_t)r * src.stride + c, ref.p + (size_t)r * ref.stride + c, sad, sum, sq);
         }
-        // svt_spatial_full_distortion_kernel_facade (picture_operators_c.c:115-174)
-        if (p.d.facade_dist)
-            p.d.facade_dist[job] = (u64)svt_hip_spy_rd_bias_inline((i64)sse, (uint32_t)w, (uint32_t)h, p.d.pred_mode[job], p.d.compound_type[job],
-                                                                   p.d.temporal_layer_index, p.d.psy_rd, p.d.spy_rd);
+    } else {
+        const float rw = __builtin_amdgcn_rcpf((float)w);
+        for (int i = lane; i < w * h; i += 64) {
+            const int r = (int)(((float)i + 0.5f) * rw), c = i - r * w; // exact for i < 2^21
+            const int d = src.at(r, c) - ref.at(r, c);
+            sad += (uint32_t)(d < 0 ? -d : d);
+            sum += d;
+            sq += (uint32_t)(d * d);
+        }
     }
-    if (p.d.satd) { // hadamard_path_c: square blocks, <= 32x32 tiles
+    sad = wave_sum_dpp(sad);
+    sum = (int32_t)wave_sum_dpp((uint32_t)sum);
+    const u64      sse  = (u64)wave_sum_dpp(sq & 0xFFFFu) + ((u64)wave_sum_dpp(sq >> 16) << 16);
+    o_sad = sad; o_sum = sum; o_sse = sse; // the outputs derived from them are written by the caller, one lane per job of the wave
+    if (p.d.satd && with_satd) { // hadamard_path_c: square blocks, <= 32x32 tiles
         uint32_t satd = 0;
         const int n = w < 32 ? w : 32;
         if (w == h && (w == 4 || w == 8 || w == 16 || w == 32 || w == 64 || w == 128)) {
             for (int ty = 0; ty < h; ty += n)
                 for (int tx = 0; tx < w; tx += n) {
-                    for (int i = lane; i < n * n; i += 64) {
-                        const int r = i / n, c = i - r * n;
-                        L.res[r * kResPitch + c] = (int16_t)((int16_t)src.at(ty + r, tx + c) - (int16_t)ref.at(ty + r, tx + c));
-                    }
+                    if (!(src.fx1 | src.fy1)) { // uniform: 4 samples per lane and step (n = 4 .. 32: powers of two)
+                        const int sh = n == 4 ? 0 : n == 8 ? 1 : n == 16 ? 2 : 3;
+                        for (int i = lane; i < (n * n) >> 2; i += 64) {
+                            const int r = i >> sh, c = 4 * (i - (r << sh));
+                            quad_residual(src.p + (size_t)(ty + r) * src.stride + tx + c, ref.p + (size_t)(ty + r) * ref.stride + tx + c, &L.res[r * kResPitch + c]);
+                        }
+                    } else
+                        for (int i = lane; i < n * n; i += 64) {
+                            const int r = i / n, c = i - r * n;
+                            L.res[r * kResPitch + c] = (int16_t)((int16_t)src.at(ty + r, tx + c) - (int16_t)ref.at(ty + r, tx + c));
+                        }
                     __syncthreads();
                     if (n >= 16) satd += hadamard_satd_mfma(L, n, lane); // uniform
                     else {
@@ -385,23 +462,84 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         satd = wave_sum(satd);
         if (lane == 0) p.d.satd[job] = satd;
     }
-    if (p.d.psy_energy || p.d.psy_dist || (p.d.psy_sse && p.d.psy_rd > 0.0)) { // svt_psy_distortion{,_hbd}: one lane per 8x8 (or 4x4) tile
-        const int n = (w >= 8 && h >= 8) ? 8 : 4, ntx = (w + n - 1) / n, nt = ntx * ((h + n - 1) / n); // the reference's loops: i < height; i += n
-        u64 total = 0;
-        for (int t = lane; t < nt; t += 64) {
-            const int ty = t / ntx, tx = t - ty * ntx;
+}
+
+template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel(const StatsParams p) {
+    __shared__ HadLds L;
+    const int      lane = threadIdx.x;
+    const uint32_t j0 = blockIdx.x * kJobsPerWave, j1 = j0 + kJobsPerWave < p.d.n_jobs ? j0 + kJobsPerWave : p.d.n_jobs;
+    // Four plain 8x8 blocks share one matrix-core tile: their residuals side by side in the LDS tile, one pair of MFMAs, four SATDs
+    bool quad8 = false;
+    if (p.d.satd && j1 - j0 == 4) { // uniform
+        const SvtHipBlockJob jb = p.d.jobs[j0 + (lane & 3)];
+        quad8 = __all(jb.width == 8 && jb.height == 8 && !(jb.subpel_x & 7) && !(jb.subpel_y & 7));
+    }
+    uint32_t my_sad = 0;
+    int32_t  my_sum = 0;
+    u64      my_sse = 0;
+    for (uint32_t job = j0; job < j1; job++) {
+        uint32_t sad;
+        int32_t  sum;
+        u64      sse;
+        block_stats_job<Pix>(p, L, job, lane, !quad8, sad, sum, sse);
+        if (lane == (int)(job - j0)) { my_sad = sad; my_sum = sum; my_sse = sse; }
+        __syncthreads(); // the LDS tile is reused by the next job
+    }
+    // svt_psy_distortion{,_hbd}: one lane per 8x8 (or 4x4) tile, the tiles of the wave's jobs side by side
+    u64 my_e = 0;
+    const bool psy = p.d.psy_energy || p.d.psy_dist || (p.d.psy_sse && p.d.psy_rd > 0.0);
+    if (psy) { // uniform
+        // per job: tile size, tiles per row, first tile of the flattened sequence (lanes 0 .. 3 compute, every lane reads them back)
+        int nt_ = 0;
+        if (lane < (int)(j1 - j0)) {
+            const SvtHipBlockJob jb = p.d.jobs[j0 + lane];
+            const int n = (jb.width >= 8 && jb.height >= 8) ? 8 : 4; // the reference's loops: i < height; i += n
+            nt_ = ((jb.width + n - 1) / n) * ((jb.height + n - 1) / n);
+        }
+        const int t1 = __builtin_amdgcn_readlane(nt_, 0), t2 = t1 + __builtin_amdgcn_readlane(nt_, 1), t3 = t2 + __builtin_amdgcn_readlane(nt_, 2),
+                  t4 = t3 + __builtin_amdgcn_readlane(nt_, 3);
+        uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0; // a job's sum stays below 2^32: 256 tiles x 64 x 64 x 1023
+        for (int t = lane; t < t4; t += 64) {
+            const int k = (t >= t1) + (t >= t2) + (t >= t3), tl = t - (k == 0 ? 0 : k == 1 ? t1 : k == 2 ? t2 : t3);
+            const SvtHipBlockJob jb = p.d.jobs[j0 + k];
+            const int n = (jb.width >= 8 && jb.height >= 8) ? 8 : 4, ntx = (jb.width + n - 1) / n;
+            const int ty = tl / ntx, tx = tl - ty * ntx;
+            const View<Pix> src = {static_cast<const Pix *>(p.d.src) + jb.src_offset, p.d.src_stride, 16 * (jb.subpel_x & 7), 16 * (jb.subpel_y & 7)};
+            const View<Pix> ref = {static_cast<const Pix *>(p.d.ref) + jb.ref_offset, p.d.ref_stride, 0, 0};
             const int32_t a = psy_tile_energy<Pix>(src.sub(ty * n, tx * n), n);
             const int32_t b = psy_tile_energy<Pix>(ref.sub(ty * n, tx * n), n);
-            total += (u64)(a > b ? a - b : b - a);
+            const uint32_t d = (uint32_t)(a > b ? a - b : b - a);
+            e0 += k == 0 ? d : 0u; e1 += k == 1 ? d : 0u; e2 += k == 2 ? d : 0u; e3 += k == 3 ? d : 0u;
         }
-        total = wave_sum(total);
-        const u64 e = sizeof(Pix) == 1 ? total >> 1 : total << 2;
-        if (lane == 0) {
-            if (p.d.psy_energy) p.d.psy_energy[job] = e;
-            if (p.d.psy_dist) p.d.psy_dist[job] = (u64)((double)e * p.d.psy_rd); // get_svt_psy_full_dist, psy_rd.c:277-293
-            if (p.d.psy_sse) p.d.psy_sse[job] = sse + (u64)((double)e * p.d.psy_rd); // svt_spatial_psy_distortion_kernel_c, picture_operators_c.c:85-112
-        }
-    } else if (p.d.psy_sse && lane == 0) p.d.psy_sse[job] = sse; // psy_rd <= 0: the plain SSE
+        e0 = wave_sum_dpp(e0); e1 = wave_sum_dpp(e1); e2 = wave_sum_dpp(e2); e3 = wave_sum_dpp(e3);
+        const u64 total = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
+        my_e = sizeof(Pix) == 1 ? total >> 1 : total << 2;
+    }
+    if (lane < (int)(j1 - j0)) { // lane k finishes job k of the wave
+        const uint32_t job = j0 + lane;
+        const SvtHipBlockJob jb = p.d.jobs[job];
+        write_pixel_outputs(p, job, jb.width, jb.height, my_sad, my_sum, my_sse);
+        if (psy) {
+            if (p.d.psy_energy) p.d.psy_energy[job] = my_e;
+            if (p.d.psy_dist) p.d.psy_dist[job] = (u64)((double)my_e * p.d.psy_rd); // get_svt_psy_full_dist, psy_rd.c:277-293
+            if (p.d.psy_sse) p.d.psy_sse[job] = my_sse + (u64)((double)my_e * p.d.psy_rd); // svt_spatial_psy_distortion_kernel_c, picture_operators_c.c:85-112
+        } else if (p.d.psy_sse) p.d.psy_sse[job] = my_sse; // psy_rd <= 0: the plain SSE
+    }
+    if (quad8) {
+        const int q = lane >> 4, r = (lane & 15) >> 1, c = 4 * (lane & 1); // block, row, first column of this lane's 4 samples
+        const SvtHipBlockJob jb = p.d.jobs[j0 + q];
+        quad_residual(static_cast<const Pix *>(p.d.src) + jb.src_offset + (size_t)r * p.d.src_stride + c, static_cast<const Pix *>(p.d.ref) + jb.ref_offset + (size_t)r * p.d.ref_stride + c,
+                      &L.res[(8 * (q >> 1) + r) * kResPitch + 8 * (q & 1) + c]);
+        __syncthreads();
+        int32_t y[4];
+        had8x4_mfma(L, 0, 0, lane, had16_weights(lane), y);
+        uint32_t sv = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sv += (uint32_t)(y[j] < 0 ? -y[j] : y[j]);
+        // block (k0 / 8, r / 8) = (lane bit 5, lane bit 3): sum over the other four lane bits
+        sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64); sv += __shfl_xor(sv, 16, 64);
+        if ((lane & 23) == 0) p.d.satd[j0 + 2 * (lane >> 5) + ((lane >> 3) & 1)] = sv;
+    }
 }
 
 // ---- svt_sad_loop_kernel: one thread per search position, first minimum in raster order through a 64-bit key ------
@@ -526,8 +664,9 @@ int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d)
     hipSetDevice(ctx->device);
     StatsParams p;
     p.d = *d;
-    if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_kernel<uint8_t>, dim3(d->n_jobs), dim3(64), 0, ctx->stream, p);
-    else hipLaunchKernelGGL(block_stats_kernel<uint16_t>, dim3(d->n_jobs), dim3(64), 0, ctx->stream, p);
+    const uint32_t grid = (d->n_jobs + kJobsPerWave - 1) / kJobsPerWave;
+    if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_kernel<uint8_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(block_stats_kernel<uint16_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }
