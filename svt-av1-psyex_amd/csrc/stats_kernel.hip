@@ -344,7 +344,7 @@ struct StatsParams {
     SvtHipBlockStatsDesc d;
 };
 
-constexpr int kJobsPerWave = 4;
+constexpr int kJobsPerWave = 4; // a multiple of 4, at most 16 (the psy prefix sum runs inside one DPP row).  Measured: 16 jobs per wave bring the 2160p psy batch from 0.29 to 0.21 ms but the 1080p statistics batch from 0.065 to 0.22 ms (sixteen 64x64 blocks in a row make a long, lonely wave)
 typedef uint32_t U32U __attribute__((aligned(1)));
 typedef uint32_t U64U __attribute__((ext_vector_type(2), aligned(2)));
 typedef short    short2v __attribute__((ext_vector_type(2)));
@@ -465,42 +465,59 @@ __device__ __forceinline__ void block_stats_job(const StatsParams &p, HadLds &L,
 }
 
 template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel(const StatsParams p) {
-    __shared__ HadLds L;
+    __shared__ HadLds   L;
+    __shared__ uint32_t tile0[kJobsPerWave + 1], esum[kJobsPerWave]; // psy: first tile of each job in the wave's tile sequence, energy sums
     const int      lane = threadIdx.x;
     const uint32_t j0 = blockIdx.x * kJobsPerWave, j1 = j0 + kJobsPerWave < p.d.n_jobs ? j0 + kJobsPerWave : p.d.n_jobs;
-    // Four plain 8x8 blocks share one matrix-core tile: their residuals side by side in the LDS tile, one pair of MFMAs, four SATDs
-    bool quad8 = false;
-    if (p.d.satd && j1 - j0 == 4) { // uniform
-        const SvtHipBlockJob jb = p.d.jobs[j0 + (lane & 3)];
-        quad8 = __all(jb.width == 8 && jb.height == 8 && !(jb.subpel_x & 7) && !(jb.subpel_y & 7));
+    const int      nj = (int)(j1 - j0);
+    // Four consecutive plain 8x8 blocks share one matrix-core tile: their residuals side by side in the LDS tile, one pair of MFMAs, four SATDs
+    uint32_t quad8 = 0; // bit g: jobs 4g .. 4g + 3 of the wave
+    if (p.d.satd) { // uniform
+        bool plain8 = false;
+        if (lane < nj) {
+            const SvtHipBlockJob jb = p.d.jobs[j0 + lane];
+            plain8 = jb.width == 8 && jb.height == 8 && !(jb.subpel_x & 7) && !(jb.subpel_y & 7);
+        }
+        const u64 m = __ballot(plain8);
+#pragma unroll
+        for (int g = 0; g < kJobsPerWave / 4; g++) quad8 |= (((m >> (4 * g)) & 0xF) == 0xF) ? 1u << g : 0u;
     }
     uint32_t my_sad = 0;
     int32_t  my_sum = 0;
     u64      my_sse = 0;
-    for (uint32_t job = j0; job < j1; job++) {
+    for (int k = 0; k < nj; k++) {
         uint32_t sad;
         int32_t  sum;
         u64      sse;
-        block_stats_job<Pix>(p, L, job, lane, !quad8, sad, sum, sse);
-        if (lane == (int)(job - j0)) { my_sad = sad; my_sum = sum; my_sse = sse; }
+        block_stats_job<Pix>(p, L, j0 + k, lane, !((quad8 >> (k >> 2)) & 1), sad, sum, sse);
+        if (lane == k) { my_sad = sad; my_sum = sum; my_sse = sse; }
         __syncthreads(); // the LDS tile is reused by the next job
     }
     // svt_psy_distortion{,_hbd}: one lane per 8x8 (or 4x4) tile, the tiles of the wave's jobs side by side
     u64 my_e = 0;
     const bool psy = p.d.psy_energy || p.d.psy_dist || (p.d.psy_sse && p.d.psy_rd > 0.0);
     if (psy) { // uniform
-        // per job: tile size, tiles per row, first tile of the flattened sequence (lanes 0 .. 3 compute, every lane reads them back)
-        int nt_ = 0;
-        if (lane < (int)(j1 - j0)) {
+        int nt = 0;
+        if (lane < nj) {
             const SvtHipBlockJob jb = p.d.jobs[j0 + lane];
             const int n = (jb.width >= 8 && jb.height >= 8) ? 8 : 4; // the reference's loops: i < height; i += n
-            nt_ = ((jb.width + n - 1) / n) * ((jb.height + n - 1) / n);
+            nt = ((jb.width + n - 1) / n) * ((jb.height + n - 1) / n);
         }
-        const int t1 = __builtin_amdgcn_readlane(nt_, 0), t2 = t1 + __builtin_amdgcn_readlane(nt_, 1), t3 = t2 + __builtin_amdgcn_readlane(nt_, 2),
-                  t4 = t3 + __builtin_amdgcn_readlane(nt_, 3);
-        uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0; // a job's sum stays below 2^32: 256 tiles x 64 x 64 x 1023
-        for (int t = lane; t < t4; t += 64) {
-            const int k = (t >= t1) + (t >= t2) + (t >= t3), tl = t - (k == 0 ? 0 : k == 1 ? t1 : k == 2 ? t2 : t3);
+        int incl = nt; // inclusive prefix over lanes 0 .. 15
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true); // row_shr:1, zero fill
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+        static_assert(kJobsPerWave <= 16, "the prefix sum runs inside one DPP row");
+        if (lane < kJobsPerWave) { tile0[lane + 1] = (uint32_t)incl; esum[lane] = 0; }
+        if (lane == 0) tile0[0] = 0;
+        __syncthreads();
+        const int total = (int)tile0[kJobsPerWave];
+        for (int t = lane; t < total; t += 64) {
+            int k = 0;
+#pragma unroll
+            for (int i = 1; i < kJobsPerWave; i++) k += t >= (int)tile0[i] ? 1 : 0; // broadcast reads
+            const int tl = t - (int)tile0[k];
             const SvtHipBlockJob jb = p.d.jobs[j0 + k];
             const int n = (jb.width >= 8 && jb.height >= 8) ? 8 : 4, ntx = (jb.width + n - 1) / n;
             const int ty = tl / ntx, tx = tl - ty * ntx;
@@ -508,14 +525,13 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
             const View<Pix> ref = {static_cast<const Pix *>(p.d.ref) + jb.ref_offset, p.d.ref_stride, 0, 0};
             const int32_t a = psy_tile_energy<Pix>(src.sub(ty * n, tx * n), n);
             const int32_t b = psy_tile_energy<Pix>(ref.sub(ty * n, tx * n), n);
-            const uint32_t d = (uint32_t)(a > b ? a - b : b - a);
-            e0 += k == 0 ? d : 0u; e1 += k == 1 ? d : 0u; e2 += k == 2 ? d : 0u; e3 += k == 3 ? d : 0u;
+            atomicAdd(&esum[k], (uint32_t)(a > b ? a - b : b - a)); // a job's sum stays below 2^32: 256 tiles x 64 x 64 x 1023
         }
-        e0 = wave_sum_dpp(e0); e1 = wave_sum_dpp(e1); e2 = wave_sum_dpp(e2); e3 = wave_sum_dpp(e3);
-        const u64 total = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : e3;
-        my_e = sizeof(Pix) == 1 ? total >> 1 : total << 2;
+        __syncthreads();
+        const u64 e = lane < kJobsPerWave ? esum[lane] : 0;
+        my_e = sizeof(Pix) == 1 ? e >> 1 : e << 2;
     }
-    if (lane < (int)(j1 - j0)) { // lane k finishes job k of the wave
+    if (lane < nj) { // lane k finishes job k of the wave
         const uint32_t job = j0 + lane;
         const SvtHipBlockJob jb = p.d.jobs[job];
         write_pixel_outputs(p, job, jb.width, jb.height, my_sad, my_sum, my_sse);
@@ -525,21 +541,23 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
             if (p.d.psy_sse) p.d.psy_sse[job] = my_sse + (u64)((double)my_e * p.d.psy_rd); // svt_spatial_psy_distortion_kernel_c, picture_operators_c.c:85-112
         } else if (p.d.psy_sse) p.d.psy_sse[job] = my_sse; // psy_rd <= 0: the plain SSE
     }
-    if (quad8) {
-        const int q = lane >> 4, r = (lane & 15) >> 1, c = 4 * (lane & 1); // block, row, first column of this lane's 4 samples
-        const SvtHipBlockJob jb = p.d.jobs[j0 + q];
-        quad_residual(static_cast<const Pix *>(p.d.src) + jb.src_offset + (size_t)r * p.d.src_stride + c, static_cast<const Pix *>(p.d.ref) + jb.ref_offset + (size_t)r * p.d.ref_stride + c,
-                      &L.res[(8 * (q >> 1) + r) * kResPitch + 8 * (q & 1) + c]);
-        __syncthreads();
-        int32_t y[4];
-        had8x4_mfma(L, 0, 0, lane, had16_weights(lane), y);
-        uint32_t sv = 0;
+    for (int g = 0; g < kJobsPerWave / 4; g++)
+        if ((quad8 >> g) & 1) { // uniform
+            const int q = lane >> 4, r = (lane & 15) >> 1, c = 4 * (lane & 1); // block, row, first column of this lane's 4 samples
+            const SvtHipBlockJob jb = p.d.jobs[j0 + 4 * g + q];
+            quad_residual(static_cast<const Pix *>(p.d.src) + jb.src_offset + (size_t)r * p.d.src_stride + c, static_cast<const Pix *>(p.d.ref) + jb.ref_offset + (size_t)r * p.d.ref_stride + c,
+                          &L.res[(8 * (q >> 1) + r) * kResPitch + 8 * (q & 1) + c]);
+            __syncthreads();
+            int32_t y[4];
+            had8x4_mfma(L, 0, 0, lane, had16_weights(lane), y);
+            uint32_t sv = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) sv += (uint32_t)(y[j] < 0 ? -y[j] : y[j]);
-        // block (k0 / 8, r / 8) = (lane bit 5, lane bit 3): sum over the other four lane bits
-        sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64); sv += __shfl_xor(sv, 16, 64);
-        if ((lane & 23) == 0) p.d.satd[j0 + 2 * (lane >> 5) + ((lane >> 3) & 1)] = sv;
-    }
+            for (int j = 0; j < 4; j++) sv += (uint32_t)(y[j] < 0 ? -y[j] : y[j]);
+            // block (k0 / 8, r / 8) = (lane bit 5, lane bit 3): sum over the other four lane bits
+            sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64); sv += __shfl_xor(sv, 16, 64);
+            if ((lane & 23) == 0) p.d.satd[j0 + 4 * g + 2 * (lane >> 5) + ((lane >> 3) & 1)] = sv;
+            __syncthreads(); // the tile is rewritten by the next group
+        }
 }
 
 // ---- svt_sad_loop_kernel: one thread per search position, first minimum in raster order through a 64-bit key ------
