@@ -757,11 +757,13 @@ __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
 
 // the wave: the window whose top-left sample is pix0 displaced by (wx0, wy0), sample by sample, coordinates clamped into the
 // padded plane.  Rare (see run_me_searches): kept out of line so that it costs the common path no registers.
-__device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const MeReq &m, int wx0, int wy0, int pitch, int rows) {
+// (its arguments are values: a request passed by reference would have to live in scratch memory on the common path as well)
+__device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const uint8_t *pix0, uint32_t stride, int min_x, int max_x, int min_y, int max_y, int wx0, int wy0,
+                                                        int pitch, int rows) {
     for (int i = threadIdx.x; i < pitch * rows; i += kThreads) {
         const int row = i / pitch, cb = i - row * pitch;
-        const int x = imin(imax(wx0 + cb, (int)m.min_x), (int)m.max_x), y = imin(imax(wy0 + row, (int)m.min_y), (int)m.max_y);
-        win[row * pitch + cb] = m.pix0[x + (long long)y * m.stride];
+        const int x = imin(imax(wx0 + cb, min_x), max_x), y = imin(imax(wy0 + row, min_y), max_y);
+        win[row * pitch + cb] = pix0[x + (long long)y * stride];
     }
 }
 
@@ -831,7 +833,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                         for (int j = 0; j < 4; j++) *reinterpret_cast<V4 *>(&LDS(sh.win)[k[j] * 16]) = v[j];
                     }
                 } else {
-                    stage_clamped(LDS(sh.win), m, wx0, wy0, pitch, rows);
+                    stage_clamped(LDS(sh.win), m.pix0, m.stride, m.min_x, m.max_x, m.min_y, m.max_y, wx0, wy0, pitch, rows);
                 }
                 wave_sync();
                 const int ng = ((shift & 3) + w + 3) >> 2;

@@ -22,7 +22,7 @@ PHASES = [
 ] + [(24 + i, f"{n}: plan a round + issue its window loads") for i, n in enumerate(STAGES)] + [(32 + i, f"{n}: window registers -> LDS arena") for i, n in enumerate(STAGES)] + [
     (40 + i, f"{n}: rest of the evaluation (tile entry -> registers, arg-min across the wave, result)") for i, n in enumerate(STAGES)] + [
     (22, "all stages: plan the next round + issue its window loads (inside the evaluation phase)"), (30, "all stages: wide tiles, item loop (8 positions x whole block per lane)"),
-    (23, "all stages: narrow tiles, item loop (4 positions x row slice per lane, LDS atomics)"), (19, "searches: tail"), (3, "8x8-variance probe (integer search at one position)"), (4, "integer search (staging, 85-PU SAD pyramid, bests)"),
+    (23, "all stages: small searches, item loop (8 positions x row slice per lane, LDS atomics)"), (19, "searches: tail"), (3, "8x8-variance probe (integer search at one position)"), (4, "integer search (staging, 85-PU SAD pyramid, bests)"),
     (5, "control after a stage (fold results, centres, early exits)"),
     (13, "reference pruning"), (14, "candidate lists"), (15, "distortions / variance outputs"), (16, "result rows stored"),
 ]
