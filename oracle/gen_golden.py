@@ -254,6 +254,19 @@ def gen_tpl_chain():
     print("tpl_chain.npz", np.stack(res).shape)
 
 
+def gen_rd_chain():
+    """The reference's RD chain (ref_harness.c:ref_rd_batch on the `_c` kernels) on tests/rd_cases.py's cases."""
+    import rd_cases
+    out = {}
+    for ci in range(len(rd_cases.CASES)):
+        f, src, pred, jobs = rd_cases.inputs(ci)
+        d = rd_cases.digest(pyoracle.rd_batch(f, src, pred, jobs, rd_cases.quant_rows(), impl="ref"))
+        for k, v in d.items():
+            out[f"c{ci}_{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "rd_chain.npz"), **out)
+    print("rd_chain.npz", len(rd_cases.CASES), "cases")
+
+
 def gen_pyramid():
     """1/4 and 1/16 luma planes with their padding as the reference's picture analysis makes them (ref_harness.c:ref_pyramid ->
     svt_aom_downsample_filtering_input_picture -> svt_aom_downsample_2d_c + svt_aom_generate_padding) for tests/pyramid_cases.py's
@@ -267,7 +280,7 @@ def gen_pyramid():
     np.savez_compressed(os.path.join(OUT, "pyramid.npz"), **out)
 
 
-GENERATORS = {"pyramid": gen_pyramid, "me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats, "dg": gen_dg_detector, "tpl": gen_tpl_chain}
+GENERATORS = {"pyramid": gen_pyramid, "me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats, "dg": gen_dg_detector, "tpl": gen_tpl_chain, "rd": gen_rd_chain}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
