@@ -416,6 +416,18 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #undef SVT_MIN_DPP
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// sum over the wave's 64 lanes (mod 2^32), in every lane's return value (SGPR), by DPP: no LDS traffic
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#define SVT_SUM_DPP(ctrl, rmask, bc) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, bc);
+    SVT_SUM_DPP(0x111, 0xF, true)  // row_shr:1 (zero fill)
+    SVT_SUM_DPP(0x112, 0xF, true)  // row_shr:2
+    SVT_SUM_DPP(0x114, 0xF, true)  // row_shr:4
+    SVT_SUM_DPP(0x118, 0xF, true)  // row_shr:8: lane 15 of a row holds the row's sum
+    SVT_SUM_DPP(0x142, 0xA, false) // row_bcast:15 -> rows 1, 3
+    SVT_SUM_DPP(0x143, 0xC, false) // row_bcast:31 -> rows 2, 3
+#undef SVT_SUM_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // the wave's smallest (sad, pos) pair as sad << 32 | pos -- the reference's "first minimum in raster order": the smallest SAD, then among
 // its lanes the smallest position word (y << 16 | x); ~0 when no lane holds a result
 __device__ __forceinline__ u64 wave_min_key(uint32_t sad, uint32_t pos) {
@@ -1069,12 +1081,33 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 st.performed_phme[li][ri][sri] = 0;
             }
         }
+        // init_zz_sad (motion_estimation.c:2382-2437) rides on the set-up: while a lane holds a 16-byte piece of the source block it fetches the
+        // same piece of every searched reference and adds up the zero-MV SAD of the even rows (get_zz_sad, :1667-1689) -- no staging, no
+        // search rounds for single positions.  Sums in zz_sum[k], k = the searched (list, reference) pairs in the reference's loop order.
+        const bool zz_on = c.me_early_exit_th || c.me_safe_limit_zz_th; // uniform
+        const int  nzz   = zz_on ? r0n + ((nl > 1 && d.temporal_layer_index > 0) ? d.num_of_ref_pic_to_search[1] : 0) : 0;
+        uint32_t   zz_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         { // source views -> LDS (every row, or the even rows only: cshift)
             const int ox = (int)(bxi * 64), oy = (int)(byi * 64), rstep = 1 << cshift;
+            const int bw64 = imin(64, (int)d.aligned_width - ox), bh64 = imin(64, (int)d.aligned_height - oy);
             for (int i = tid; i < (64 >> cshift) * 4; i += kThreads) {
                 const int row = i >> 2, cc = i & 3;
                 uint4 v; memcpy(&v, plane_at(p.cur.lvl[2], ox + cc * 16, oy + row * rstep), 16);
                 *reinterpret_cast<uint4 *>(&LDS(sh.src64)[row * kSrc64Pitch + cc * 16]) = v;
+                const int y = row * rstep, x = cc * 16;
+                if (nzz && !(y & 1) && y < bh64 && x < bw64) { // block widths are multiples of 8: a piece is whole or half inside
+                    const bool whole = x + 8 < bw64;
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (k < nzz) { // uniform
+                            const int li = k < r0n ? 0 : 1, ri = k < r0n ? k : k - r0n;
+                            uint4 w; memcpy(&w, plane_at(p.ref[li][ri].lvl[2], ox + x, oy + y), 16);
+                            uint32_t a = __builtin_amdgcn_sad_u8(v.x, w.x, zz_sum[k]);
+                            a = __builtin_amdgcn_sad_u8(v.y, w.y, a);
+                            if (whole) { a = __builtin_amdgcn_sad_u8(v.z, w.z, a); a = __builtin_amdgcn_sad_u8(v.w, w.w, a); }
+                            zz_sum[k] = a;
+                        }
+                }
             }
             for (int i = tid; i < (32 >> cshift) * 2; i += kThreads) {
                 const int row = i >> 1, cc = i & 1;
@@ -1086,6 +1119,12 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 *reinterpret_cast<uint4 *>(&LDS(sh.src16)[i * kSrc16Pitch]) = v;
             }
         }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < nzz) { // uniform
+                const uint32_t t = wave_sum_u32(zz_sum[k]);
+                if (tid == 0) st.req_key[k] = (u64)t << 32; // where zz_post looks for the result of search k
+            }
         wave_sync();
 
         PROF(1);
@@ -1094,12 +1133,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         // pushes its searches and a "post" part that folds the results into the block state.
         // ---- init_zz_sad (motion_estimation.c:2382-2437) ------------------------------------------------
         auto zz_pre = [&]() {
-            if (tid == 0) {
-                st.nreq = 0;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
-                        if (searched(p, li)) push_zz_req(st, p.ref[li][ri].lvl[2], 0, 0);
-            }
+            if (tid == 0) st.nreq = 0; // the SADs came with the block set-up
         };
         auto zz_post = [&]() {
             if (tid == 0) {
