@@ -199,6 +199,14 @@ int  svt_hip_pa_picture_create_dev(SvtHipContext *ctx, const SvtHipPlaneDesc *fu
  * the same geometry and rebuild the 1/4 and 1/16 planes on the device; enqueued on the context stream (asynchronous when `full` is page-locked
  * host memory or, with full_on_device != 0, device memory). */
 int  svt_hip_pa_picture_update(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device);
+/* The same refill on the context's TRANSFER stream, so that the copy (and the two decimation launches) run beside the kernels of the
+ * context stream: ordered behind everything enqueued on the context stream before this call -- whatever may still read the picture's old
+ * content -- and beside everything enqueued after it; every entry that reads the picture waits for it through the picture's event.  The
+ * usual pipeline: enqueue step k, refill the pictures of step k + 1, enqueue step k + 1, ...  `full` must be page-locked host memory (or device
+ * memory) for the copy to be asynchronous.  svt_hip_context_transfer_stream() hands the stream out for the caller's own copies (e.g. results
+ * back to the host behind an event recorded on the context stream). */
+int  svt_hip_pa_picture_update_ahead(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device);
+void *svt_hip_context_transfer_stream(SvtHipContext *ctx);
 void svt_hip_pa_picture_destroy(SvtHipContext *ctx, SvtHipPaPicture *pic);
 /* copies level (0 = sixteenth, 1 = quarter, 2 = full) back into a host plane of identical geometry */
 int  svt_hip_pa_picture_download(SvtHipContext *ctx, const SvtHipPaPicture *pic, int level, uint8_t *dst,

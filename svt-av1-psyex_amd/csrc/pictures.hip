@@ -50,10 +50,10 @@ int check_plane(SvtHipContext *ctx, const SvtHipPlaneDesc *p, int min_pad, const
     return SVT_HIP_OK;
 }
 
-int upload_plane(SvtHipContext *ctx, const SvtHipPlaneDesc *h, DevPlane *d, bool from_device) {
+int upload_plane(SvtHipContext *ctx, const SvtHipPlaneDesc *h, DevPlane *d, bool from_device, hipStream_t stream = nullptr) {
     const size_t w = (size_t)h->width + 2 * (size_t)h->org_x, rows = (size_t)h->height + 2 * (size_t)h->org_y;
     SVT_HIP_CHECK(ctx, hipMemcpy2DAsync(const_cast<uint8_t *>(d->base), d->stride, h->buffer_y, h->stride_y, w, rows,
-                                        from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+                                        from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream ? stream : ctx->stream));
     return SVT_HIP_OK;
 }
 
@@ -149,6 +149,8 @@ void svt_hip_context_destroy(SvtHipContext *ctx) {
         }
         if (l.stream) hipStreamDestroy(l.stream);
     }
+    if (ctx->io_stream) { hipStreamSynchronize(ctx->io_stream); hipStreamDestroy(ctx->io_stream); }
+    if (ctx->io_fence) hipEventDestroy(ctx->io_fence);
     svt_hip_rd_tables_free(ctx);
     delete ctx;
 }
@@ -159,6 +161,7 @@ void       *svt_hip_context_stream(SvtHipContext *ctx) { return ctx ? (void *)ct
 int svt_hip_context_sync(SvtHipContext *ctx) {
     if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
     SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->io_stream) SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->io_stream));
     return SVT_HIP_OK;
 }
 
@@ -174,25 +177,55 @@ int svt_hip_pa_picture_create_dev(SvtHipContext *ctx, const SvtHipPlaneDesc *ful
 // A picture buffer taken from a pool and filled with the next input picture (the reference recycles its EbPaReferenceObject buffers the
 // same way, Codec/reference_object.c): the full plane is copied in again (from page-locked host memory the copy is asynchronous), the
 // 1/4 and 1/16 planes are rebuilt on the device.  Enqueued on the context stream.
-int svt_hip_pa_picture_update(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device) {
-    if (!ctx || !pic) return SVT_HIP_ERR_BAD_PARAM;
+static int picture_update_on(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device, hipStream_t stream) {
     int rc = check_plane(ctx, full, 64, "full");
     if (rc) return rc;
     DevPlane &f = pic->pyr.lvl[2];
     if (full->width != f.width || full->height != f.height || full->org_x != f.org_x || full->org_y != f.org_y)
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "update: plane %ux%u pad %u,%u does not match the picture's %dx%d pad %d,%d", full->width, full->height,
                             full->org_x, full->org_y, f.width, f.height, f.org_x, f.org_y);
-    hipSetDevice(ctx->device);
-    if ((rc = upload_plane(ctx, full, &f, full_on_device != 0))) return rc;
+    if ((rc = upload_plane(ctx, full, &f, full_on_device != 0, stream))) return rc;
     for (int level = 1; level >= 0; level--) {
         const DevPlane &src = pic->pyr.lvl[level + 1], &dst = pic->pyr.lvl[level];
         const int pw = dst.width + 2 * dst.org_x, ph = dst.height + 2 * dst.org_y;
-        hipLaunchKernelGGL(downsample2x_pad_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, ctx->stream, src, dst);
+        hipLaunchKernelGGL(downsample2x_pad_kernel, dim3((pw + 255) / 256, ph), dim3(256), 0, stream, src, dst);
     }
     SVT_HIP_CHECK(ctx, hipGetLastError());
-    SVT_HIP_CHECK(ctx, hipEventRecord(pic->ready, ctx->stream));
-    pic->ready_stream = ctx->stream;
+    SVT_HIP_CHECK(ctx, hipEventRecord(pic->ready, stream));
+    pic->ready_stream = stream;
     return SVT_HIP_OK;
+}
+
+int svt_hip_pa_picture_update(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device) {
+    if (!ctx || !pic) return SVT_HIP_ERR_BAD_PARAM;
+    hipSetDevice(ctx->device);
+    return picture_update_on(ctx, pic, full, full_on_device, ctx->stream);
+}
+
+// The refill on the context's transfer stream: ordered behind everything enqueued on the context stream so far (whatever still reads the
+// picture's old content), beside whatever is enqueued afterwards; readers wait through the picture's `ready` event.
+int svt_hip_pa_picture_update_ahead(SvtHipContext *ctx, SvtHipPaPicture *pic, const SvtHipPlaneDesc *full, int full_on_device) {
+    if (!ctx || !pic) return SVT_HIP_ERR_BAD_PARAM;
+    hipSetDevice(ctx->device);
+    std::lock_guard<std::mutex> lock(ctx->async_mu);
+    if (!ctx->io_stream) {
+        SVT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->io_stream, hipStreamNonBlocking));
+        SVT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->io_fence, hipEventDisableTiming));
+    }
+    SVT_HIP_CHECK(ctx, hipEventRecord(ctx->io_fence, ctx->stream));
+    SVT_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->io_stream, ctx->io_fence, 0));
+    return picture_update_on(ctx, pic, full, full_on_device, ctx->io_stream);
+}
+
+void *svt_hip_context_transfer_stream(SvtHipContext *ctx) {
+    if (!ctx) return nullptr;
+    std::lock_guard<std::mutex> lock(ctx->async_mu);
+    if (!ctx->io_stream) {
+        hipSetDevice(ctx->device);
+        if (hipStreamCreateWithFlags(&ctx->io_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&ctx->io_fence, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return (void *)ctx->io_stream;
 }
 
 void svt_hip_pa_picture_destroy(SvtHipContext *ctx, SvtHipPaPicture *pic) {
@@ -224,6 +257,7 @@ int svt_hip_pa_picture_download(SvtHipContext *ctx, const SvtHipPaPicture *pic, 
     const DevPlane &p = pic->pyr.lvl[level];
     const size_t    w = (size_t)p.width + 2 * (size_t)p.org_x, rows = (size_t)p.height + 2 * (size_t)p.org_y;
     if (dst_stride < w) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "dst_stride %u < %zu", dst_stride, w);
+    if (int rc = svt_hip_wait_picture(ctx, ctx->stream, pic)) return rc; // filled on another stream (a refill ahead): wait for it
     SVT_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dst_stride, p.base, p.stride, w, rows, hipMemcpyDeviceToHost, ctx->stream));
     SVT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SVT_HIP_OK;

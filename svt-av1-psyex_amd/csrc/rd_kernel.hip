@@ -316,7 +316,6 @@ template <int N, int FM> __device__ __forceinline__ void fwd_1d(int32_t *x, int 
 // pass with weights of magnitude <= 1, so with the up-shift of at most 2 in front of the column pass and the down-shifts between the passes
 // (fwd_txfm_shift_ls, transforms.h:27-45) no node of any of the 19 sizes exceeds 64 * 65,520 < 2^22; the cosine weights are < 2^14.  Any
 // 8- / 10-bit picture satisfies it; samples outside the bit depth (the reference accepts any uint16) take the 32-bit path.
-constexpr int kFwdMul24MaxResidual = 4095;
 // The three-instruction butterflies (hbtf<2>) need every node of the pass below 2^17: N x the largest input of the pass (measured over the wave).
 __device__ __forceinline__ bool pass_fits_17_bits(uint32_t wave_max_abs_input, int n) { return (unsigned long long)wave_max_abs_input * (unsigned)n < (1u << 17); }
 template <int N, int CLAMP, int IM> __device__ __forceinline__ void inv_1d(int32_t *x, int type) {

@@ -43,6 +43,8 @@ struct SvtHipContext {
     int16_t    *iscan_dev;             // [19][3][1024] inverse scan orders (rd_kernel.hip), this device's copy
     bool        me_attr_set;           // hipFuncSetAttribute done for the ME kernel on this device
     uint32_t    me_waves_per_cu;       // 0: as many persistent ME waves per CU as fit; else an upper limit (svt_hip_context_set_me_waves_per_cu)
+    hipStream_t io_stream;             // transfer stream of svt_hip_pa_picture_update_ahead (created on first use)
+    hipEvent_t  io_fence;              // orders the transfer stream behind the context stream
 };
 
 struct SvtHipPaPicture {

@@ -52,3 +52,32 @@ def test_device_pyramid_matches_reference_fixture(hip_ctx, name):
         assert np.array_equal(pic.download(0), z[name + "_s"]), "sixteenth"
     finally:
         pic.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["svt_hip_pa_picture_update", "svt_hip_pa_picture_update_ahead"])
+def test_picture_refill_rebuilds_the_pyramid(hip_ctx, entry):
+    """A pooled picture object refilled with another picture (on the context stream, or ahead on the transfer stream): every level equals the
+    fixture of the new content, and a download / ME launch issued right behind the refill sees it (the picture's event orders them)."""
+    import ctypes as C
+
+    from svt_av1_psyex_amd import api
+    z = np.load(GOLDEN)
+    names = list(CASES)[:1]
+    first = synth.HostPyramid(luma(*CASES[names[0]]))
+    pic = hip_ctx.upload(first, device_pyramid=True)
+    try:
+        other = synth.HostPyramid(np.ascontiguousarray(luma(*CASES[names[0]])[::-1, ::-1]))  # same geometry, other content
+        full = other.desc(2)
+        hip_ctx.check(getattr(api.lib(), entry)(hip_ctx._h, pic._h, C.byref(full), 0), entry)
+        want = hip_ctx.upload(other, device_pyramid=True)
+        try:
+            for level in (0, 1, 2):  # the download waits for the picture's event
+                assert np.array_equal(pic.download(level), want.download(level)), level
+        finally:
+            want.free()
+        back = first.desc(2)
+        hip_ctx.check(getattr(api.lib(), entry)(hip_ctx._h, pic._h, C.byref(back), 0), entry)
+        assert np.array_equal(pic.download(1), z[names[0] + "_q"]) and np.array_equal(pic.download(0), z[names[0] + "_s"])
+    finally:
+        pic.free()
