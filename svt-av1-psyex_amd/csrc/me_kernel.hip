@@ -701,6 +701,101 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
     }
 }
 
+// A stage whose searches are all SMALL and alike (the HME level-1 / level-2 refinements: 8 x 3 positions around eight centres on a 32 x 32 /
+// 64 x 64 block) skips the arena: the octets of positions of ALL its searches are spread over the lanes together with slices of the block
+// rows, and a lane fetches its window rows straight from global memory (a row is NDW + 2 dwords: two or five unaligned 16-byte loads, the
+// next row on its way while the current one is evaluated) -- no tile plan, no staging rounds, one pass for the whole stage.  Per-position
+// sums meet in the (idle) arena by LDS atomics; one arg-min per search.  Returns false (nothing done) when the stage does not qualify.
+template <int NDW>
+__device__ __forceinline__ void direct_rows(const uint8_t *src, int sp, int srs, const uint8_t *wp, long long wstep, int e0, int e1, uint32_t out[8]) {
+    constexpr int NV = (NDW + 2 + 3) / 4, kRowsPerFlush = 64 / NDW;
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    V4U cur[NV], nxt[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) cur[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(wp) + 16 * k);
+    for (int eb = e0; eb < e1; eb += kRowsPerFlush) {
+        const int ee = eb + kRowsPerFlush < e1 ? eb + kRowsPerFlush : e1;
+        u64       acc0 = 0, acc1 = 0;
+        for (int e = eb; e < ee; e++) {
+            wp += wstep;
+            if (e + 1 < e1) { // the next row is on its way while this one is evaluated
+#pragma unroll
+                for (int k = 0; k < NV; k++) nxt[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(wp) + 16 * k);
+            }
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + e * srs * sp);
+            uint32_t sv[NDW], wv[4 * NV];
+#pragma unroll
+            for (int j = 0; j < NDW; j += 4) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(s + j);
+                sv[j] = q.x; sv[j + 1] = q.y; sv[j + 2] = q.z; sv[j + 3] = q.w;
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) { wv[4 * k] = cur[k].x; wv[4 * k + 1] = cur[k].y; wv[4 * k + 2] = cur[k].z; wv[4 * k + 3] = cur[k].w; }
+#pragma unroll
+            for (int j = 0; j < NDW; j++) {
+                acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 1] << 32) | wv[j], sv[j], acc0);
+                acc1 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 2] << 32) | wv[j + 1], sv[j], acc1);
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) cur[k] = nxt[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] += (uint32_t)((acc0 >> (16 * i)) & 0xFFFF); a[4 + i] += (uint32_t)((acc1 >> (16 * i)) & 0xFFFF); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = a[i];
+}
+
+__device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
+    St       &st   = sh.st;
+    const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
+    // every search like the first one, few positions, whole-vector source rows
+    const Req &r0 = st.req[0];
+    const int  w = (int16_t)uni((uint32_t)r0.sa_w), h = (int16_t)uni((uint32_t)r0.sa_h), bw = (int)uni(r0.bw), bh = (int)uni(r0.bh), rs = (int)uni(r0.rs),
+               level = (int)uni(r0.level);
+    bool ok = true;
+    if (lane < nreq) {
+        const Req &r = st.req[lane];
+        ok = r.sa_w == w && r.sa_h == h && r.bw == bw && r.bh == bh && r.rs == rs && r.level == level && !r.skip_even;
+    }
+    if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
+    const int ng = (w + 7) >> 3, per = ng * h, Q = per * nreq; // octet items of one slice
+    if (Q > kThreads) return false;
+    int       S        = imin(bh, (int)uni(div_by_rcp((uint32_t)kThreads, rcp_of((uint32_t)Q))));
+    const int rows_per = (int)uni(div_by_rcp((uint32_t)(bh + S - 1), rcp_of((uint32_t)S)));
+    S                  = (int)uni(div_by_rcp((uint32_t)(bh + rows_per - 1), rcp_of((uint32_t)rows_per)));
+    uint32_t *sad = reinterpret_cast<uint32_t *>(LDS(sh.win)); // [nreq][kNarrowMaxPos]
+    for (int p = lane; p < nreq * kNarrowMaxPos; p += kThreads) sad[p] = 0;
+    wave_sync();
+    const uint8_t *src = src_view(sh, level);
+    const int      sp  = (level == 2) ? kSrc64Pitch : (level == 1 ? kSrc32Pitch : kSrc16Pitch), srs = rs >> sh.cshift;
+    if (lane < Q * S) {
+        const int slice = (int)div_by_rcp((uint32_t)lane, rcp_of((uint32_t)Q)), q = lane - slice * Q;
+        const int req = (int)div_by_rcp((uint32_t)q, rcp_of((uint32_t)per)), ql = q - req * per;
+        const int y = (int)div_by_rcp((uint32_t)ql, rcp_of((uint32_t)ng)), g = ql - y * ng;
+        const Req &r = st.req[req];
+        const long long wstep = (long long)rs * (long long)r.stride;
+        const int e0 = slice * rows_per, e1 = imin(e0 + rows_per, bh);
+        const uint8_t *wp = r.win + (long long)y * r.stride + (long long)e0 * wstep + 8 * g;
+        uint32_t s8[8];
+        if (bw == 64) direct_rows<16>(src, sp, srs, wp, wstep, e0, e1, s8);
+        else direct_rows<8>(src, sp, srs, wp, wstep, e0, e1, s8);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (8 * g + i < w) atomicAdd(&sad[req * kNarrowMaxPos + y * w + 8 * g + i], s8[i]);
+    }
+    wave_sync();
+    PROF(23);
+    const float w_rcp = rcp_of((uint32_t)w);
+    for (int req = 0; req < nreq; req++) { // lane <-> position in raster order: the first minimum is the smallest (sad << 6 | lane) (sad < 2^20)
+        const uint32_t k32 = wave_min_u32(lane < w * h ? (sad[req * kNarrowMaxPos + lane] << 6) | (uint32_t)lane : 0xFFFFFFFFu);
+        const int      wl = (int)(k32 & 63u), wy = (int)uni(div_by_rcp((uint32_t)wl, w_rcp)), wx = wl - wy * w;
+        if (lane == 0) st.req_key[req] = ((u64)(k32 >> 6) << 32) | ((uint32_t)wy << 16) | (uint32_t)wx;
+    }
+    wave_sync(); // the arena is free again
+    return true;
+}
+
 // slot < 0: append (serial pushes by lane 0); otherwise the caller owns st.req[slot] and sets st.nreq itself (lane-parallel pushes)
 __device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t stride, int sa_w, int sa_h, int bw, int bh, int rs,
                                          int level, int skip, int slot = -1) {
@@ -1561,7 +1656,9 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 if (step == kC00 && bi == 0 && st.tf_exit) { step = kEnd; continue; } // uniform: LDS value read after the barrier
                 if (step < kProbe) {
                     PROF_STEP(step);
-                    if (st.nreq) run_searches(sh PROF_ARG); // uniform (LDS value read after the barrier)
+                    if (st.nreq) { // uniform (LDS value read after the barrier)
+                        if (!run_small_searches_direct(sh PROF_ARG)) run_searches(sh PROF_ARG);
+                    }
                 } else {
                     const bool   probe = step == kProbe;
                     const MeReq *list  = probe ? st.me_probe : st.me;
