@@ -140,8 +140,10 @@ typedef struct SvtHipMeResults {
     uint32_t *rc_me_distortion, *me_8x8_cost_variance;
     uint8_t  *stationary_block_present_sb, *rc_me_allow_gm;
     /* optional search-level results (may be NULL): MeContext.p_sb_best_sad / p_sb_best_mv and search_results.
-     * Layout [n_b64][2][4][85] in the reference's n_idx order; entries of refs that were pruned
-     * (do_ref == 0) or not searched hold SVT_HIP_MAX_SAD_VALUE / 0. */
+     * Layout [n_b64][2][4][85] in the reference's n_idx order; entries of refs that were pruned (do_ref == 0) hold SVT_HIP_MAX_SAD_VALUE / 0.
+     * The slots of (list, reference) pairs the picture does not search at all (list >= num_of_list_to_search, ref >= num_of_ref_pic_to_search[list])
+     * hold the same values after svt_hip_me_picture; the asynchronous entries do not touch them (the reference's MeContext arrays hold stale
+     * data there: nothing reads them) -- a quarter of the result bytes of a two-reference picture instead of all of them. */
     uint32_t *sb_best_sad, *sb_best_mv;
     int16_t  *hme_sc;  /* [n_b64][2][4][2] (x,y) */
     uint32_t *hme_sad; /* [n_b64][2][4] low 32 bits of SearchResults.hme_sad after me_prune_ref */

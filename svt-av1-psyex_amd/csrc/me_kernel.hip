@@ -1894,12 +1894,13 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
           }
             PROF(15);
             // ---- optional search-level results ------------------------------------------------------------------
-            if (p.res.sb_best_sad || p.res.sb_best_mv)
-                for (int i = tid; i < 2 * 4 * 85; i += kThreads) {
-                    const int li = i / (4 * 85), ri = (i / 85) & 3, nn = i % 85;
-                    const bool ok = li < nl && ri < d.num_of_ref_pic_to_search[li] && st.do_ref[li][ri];
-                    if (p.res.sb_best_sad) p.res.sb_best_sad[(size_t)b * 680 + i] = ok ? BEST_SAD(li, ri)[nn] : SVT_HIP_MAX_SAD_VALUE;
-                    if (p.res.sb_best_mv) p.res.sb_best_mv[(size_t)b * 680 + i] = ok ? BEST_MV(li, ri)[nn] : 0;
+            if (p.res.sb_best_sad || p.res.sb_best_mv) // the slots of the (list, reference) pairs the picture searches; the others are left alone
+                for (int i = tid; i < n_rows * 85; i += kThreads) {
+                    const int row = i / 85, nn = i - row * 85, li = row < r0n ? 0 : 1, ri = row < r0n ? row : row - r0n;
+                    const bool   ok = st.do_ref[li][ri] != 0;
+                    const size_t o  = (size_t)b * 680 + (size_t)(li * 4 + ri) * 85 + nn;
+                    if (p.res.sb_best_sad) p.res.sb_best_sad[o] = ok ? bsad[i] : SVT_HIP_MAX_SAD_VALUE;
+                    if (p.res.sb_best_mv) p.res.sb_best_mv[o] = ok ? bmv[i] : 0;
                 }
             if (tid < 8) {
                 const int li = tid >> 2, ri = tid & 3;

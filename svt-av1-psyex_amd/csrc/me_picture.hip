@@ -184,6 +184,19 @@ int svt_hip_me_picture(SvtHipContext *ctx, const SvtHipMeConfig *cfg, const SvtH
                                           lane->stream));
     }
     SVT_HIP_CHECK(ctx, hipStreamSynchronize(lane->stream));
+    // The kernel writes the search-level arrays for the (list, reference) pairs the picture searches only; this entry hands back whole
+    // arrays with the canonical values in the other slots
+    if (res->sb_best_sad || res->sb_best_mv)
+        for (size_t b = (size_t)g.row0 * g.w64; b < (size_t)(g.row0 + g.nrow) * g.w64; b++)
+            for (int li = 0; li < SVT_HIP_MAX_LISTS; li++)
+                for (int ri = 0; ri < SVT_HIP_MAX_REFS; ri++) {
+                    if (li < desc->num_of_list_to_search && ri < desc->num_of_ref_pic_to_search[li]) continue;
+                    const size_t o = b * 680 + (size_t)(li * 4 + ri) * 85;
+                    for (int n = 0; n < 85; n++) {
+                        if (res->sb_best_sad) res->sb_best_sad[o + n] = SVT_HIP_MAX_SAD_VALUE;
+                        if (res->sb_best_mv) res->sb_best_mv[o + n] = 0;
+                    }
+                }
     return SVT_HIP_OK;
 }
 

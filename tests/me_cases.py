@@ -106,6 +106,21 @@ def compare(a, b, names=None):
     return bad
 
 
+def fill_unsearched(desc, got, max_sad=128 * 128 * 255):
+    """The asynchronous ME entries leave the search-level slots of (list, reference) pairs the picture does not search untouched
+    (include/svt_hip_me.h); svt_hip_me_picture and the oracle hold SVT_HIP_MAX_SAD_VALUE / 0 there: bring a result read back from a device
+    buffer to that form before comparing."""
+    for name, val in (("sb_best_sad", max_sad), ("sb_best_mv", 0)):
+        if name not in got:
+            continue
+        a = got[name].reshape(-1, 2, 4, 85)
+        for li in range(2):
+            for ri in range(4):
+                if not (li < desc.num_of_list_to_search and ri < desc.num_of_ref_pic_to_search[li]):
+                    a[:, li, ri, :] = val
+    return got
+
+
 MCTF_OUTPUTS = ("sb_best_sad", "sb_best_mv", "hme_sc", "hme_sad", "do_ref")  # what ME_MCTF produces (motion_estimation.c:3126)
 
 MCTF_GRID = [

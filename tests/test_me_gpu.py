@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from golden_io import GoldenMeCase, me_fixture_names
-from me_cases import MCTF_GRID, MCTF_OUTPUTS, MeCase, compare
+from me_cases import MCTF_GRID, MCTF_OUTPUTS, MeCase, compare, fill_unsearched
 from test_oracle_vs_ref import ME_GRID
 
 pytestmark = pytest.mark.gpu
@@ -168,7 +168,7 @@ def test_several_pictures_in_one_launch(hip_ctx):
     hip_ctx.me_pictures_async(jobs)
     hip_ctx.sync()
     for c, (bufs, nb, n), exp in zip(cases, keep, expect):
-        got = {name: bufs[name].cpu().numpy().view(dt).reshape(nb, -1) for name, dt, _ in abi.RESULT_FIELDS}
+        got = fill_unsearched(c.desc, {name: bufs[name].cpu().numpy().view(dt).reshape(nb, -1) for name, dt, _ in abi.RESULT_FIELDS})
         w64 = (c.desc.aligned_width + 63) // 64
         r0 = c.desc.b64_row_start
         r1 = r0 + (c.desc.b64_row_count or ((c.desc.aligned_height + 63) // 64 - r0))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from dg_cases import DgCase
-from me_cases import MeCase, compare
+from me_cases import MeCase, compare, fill_unsearched
 
 pytestmark = pytest.mark.gpu
 
@@ -122,7 +122,7 @@ def test_async_launch_ahead(hip_ctx):
         hip_ctx.me_picture_async(c.cfg, c.desc, cur, refs, res)
     hip_ctx.sync()
     for i, (_, keep) in enumerate(bufs):
-        got = {name: t.cpu().numpy().view(dt).reshape(alone[i][name].shape) for name, (t, dt) in keep.items()}
+        got = fill_unsearched(cases[i].desc, {name: t.cpu().numpy().view(dt).reshape(alone[i][name].shape) for name, (t, dt) in keep.items()})
         assert not compare(alone[i], got), i
     for cur, refs in dev:
         cur.free()
