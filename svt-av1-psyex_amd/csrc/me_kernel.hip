@@ -1499,23 +1499,25 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 }
                 // ME_MCTF leaves after HME when list0/ref0 already matches (motion_estimation.c:3109-3113)
                 st.tf_exit = mctf && st.hme_sad64[0][0] < (u64)d.tf_me_exit_th;
-                if (c.enable_hme_flag && !mctf) { // hme_prune_ref_and_adjust_sr is skipped for ME_MCTF (:3103,3115)
-                    const uint16_t th = c.prune_ref_if_hme_sad_dev_bigger_than_th;
-                    if (c.enable_me_hme_ref_pruning && th != 0xFFFF) {
-                        u64 best = ~0ull;
-                        for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) best = st.hme_sad64[li][ri] < best ? st.hme_sad64[li][ri] : best;
-                        for (int li = 0; li < 2; li++) for (int ri = 1; ri < 4; ri++)
-                            if ((st.hme_sad64[li][ri] - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
-                    }
-                    if (c.enable_me_sr_adjustment)
-                        for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) {
-                            if (iabs(st.hme_sc_x[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th && iabs(st.hme_sc_y[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th &&
-                                st.hme_sad64[li][ri] < c.stationary_hme_sad_abs_th)
-                                st.sr_divisor[li][ri] = c.stationary_me_sr_divisor;
-                            else if (st.hme_sad64[li][ri] < c.reduce_me_sr_based_on_hme_sad_abs_th)
-                                st.sr_divisor[li][ri] = c.me_sr_divisor_for_low_hme_sad;
-                        }
+            }
+            if (c.enable_hme_flag && !mctf) { // hme_prune_ref_and_adjust_sr (skipped for ME_MCTF, :3103,3115): lane <-> (list, reference)
+                wave_sync();
+                const int  li = (tid >> 2) & 1, ri = tid & 3;
+                const bool slot = tid < 8; // the slots beyond the searched references hold the initial 0xFFFFFFFF / centre (0, 0): never the minimum
+                const u64  hs = slot ? st.hme_sad64[li][ri] : ~0ull;
+                const uint16_t th = c.prune_ref_if_hme_sad_dev_bigger_than_th;
+                if (c.enable_me_hme_ref_pruning && th != 0xFFFF) {
+                    const u64 best = (u64)wave_min_u32((uint32_t)(hs < 0xFFFFFFFFull ? hs : 0xFFFFFFFFull)); // hme_sad is a 32-bit quantity here
+                    if (slot && ri >= 1 && (hs - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
                 }
+                if (c.enable_me_sr_adjustment && slot) {
+                    if (iabs(st.hme_sc_x[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th && iabs(st.hme_sc_y[li][ri]) <= c.reduce_me_sr_based_on_mv_length_th &&
+                        hs < c.stationary_hme_sad_abs_th)
+                        st.sr_divisor[li][ri] = c.stationary_me_sr_divisor;
+                    else if (hs < c.reduce_me_sr_based_on_hme_sad_abs_th)
+                        st.sr_divisor[li][ri] = c.me_sr_divisor_for_low_hme_sad;
+                }
+                wave_sync(); // lane 0 reads what lanes 1 .. 7 wrote
             }
         };
         // ---- integer_search_b64 (motion_estimation.c:1249-1516) --------------------------------------------
@@ -1707,13 +1709,14 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 if ((tid & 63) == 0) st.hme_sad64[li][ri] = t;
             }
             wave_sync();
-            if (tid == 0) {
+            {
                 const uint16_t th = c.prune_ref_if_me_sad_dev_bigger_than_th;
-                if (th != 0xFFFF) {
-                    u64 best = ~0ull;
-                    for (int li = 0; li < 2; li++) for (int ri = 0; ri < 4; ri++) best = st.hme_sad64[li][ri] < best ? st.hme_sad64[li][ri] : best;
-                    for (int li = 0; li < 2; li++) for (int ri = 1; ri < 4; ri++)
-                        if ((st.hme_sad64[li][ri] - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
+                if (th != 0xFFFF) { // lane <-> (list, reference); every value is below 2^32 (64 x MAX_SAD_VALUE, or the initial 0xFFFFFFFF)
+                    const int  li = (tid >> 2) & 1, ri = tid & 3;
+                    const bool slot = tid < 8;
+                    const u64  hs = slot ? st.hme_sad64[li][ri] : ~0ull;
+                    const u64  best = (u64)wave_min_u32((uint32_t)(hs < 0xFFFFFFFFull ? hs : 0xFFFFFFFFull));
+                    if (slot && ri >= 1 && (hs - best) * 100 > (u64)th * best) st.do_ref[li][ri] = 0;
                 }
             }
             wave_sync();
