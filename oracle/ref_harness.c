@@ -465,7 +465,7 @@ void ref_set_simd_rd(int use_simd) {
 int ref_rd_batch(const SvtHipRdBatchDesc *d) {
     const int ts = d->tx_size;
     if (!g_fwd[0]) ref_set_simd_rd(0);
-    if (ts < 0 || ts > 4 || d->quant_kind != 0) return 2; /* square sizes, "b" quantizer */
+    if (ts < 0 || ts > 18 || d->quant_kind > 1 || d->qmatrix) return 2; /* every size, "b" and "fp" quantizers, flat matrices, full transforms */
     const int W = tx_size_wide[ts], H = tx_size_high[ts], WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
     const int bd = d->bit_depth, hbd = bd != 8, log_scale = av1_get_tx_scale_tab[ts];
     int16_t  *res = aligned_alloc(64, sizeof(int16_t) * W * H);
@@ -481,12 +481,24 @@ int ref_rd_batch(const SvtHipRdBatchDesc *d) {
         for (int k = 0; k < 8; k++) { zbin[k] = qr->zbin[k != 0]; rnd[k] = qr->round[k != 0]; qnt[k] = qr->quant[k != 0]; qsh[k] = qr->quant_shift[k != 0]; deq[k] = qr->dequant[k != 0]; }
         if (hbd) svt_residual_kernel16bit((uint16_t *)d->src + jb->src_offset, d->src_stride, (uint16_t *)d->pred + jb->pred_offset, d->pred_stride, res, W, W, H);
         else svt_residual_kernel8bit((uint8_t *)d->src + jb->src_offset, d->src_stride, (uint8_t *)d->pred + jb->pred_offset, d->pred_stride, res, W, W, H);
+        if (jb->pf_shape) return 2;
         g_fwd[ts](res, co, W, tt, (uint8_t)bd);
-        d->three_quad_energy[j] = ts == 4 ? svt_handle_transform64x64(co) : 0;
+        /* 64-point dimensions: the energy outside the top-left 32 x 32 and the packing of what is kept (transforms.c:2374-2505) */
+        d->three_quad_energy[j] = ts == 4 ? svt_handle_transform64x64(co) : ts == 11 ? svt_handle_transform32x64(co) : ts == 12 ? svt_handle_transform64x32(co)
+            : ts == 17 ? svt_handle_transform16x64(co) : ts == 18 ? svt_handle_transform64x16(co) : 0;
         d->satd[j]              = (uint32_t)svt_aom_satd(co, NP);
         const ScanOrder *so = &av1_scan_orders[ts][tt];
-        if (hbd) svt_aom_highbd_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
-        else svt_aom_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
+        if (d->quant_kind == 0) {
+            if (hbd) svt_aom_highbd_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
+            else svt_aom_quantize_b(co, NP, zbin, rnd, qnt, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, NULL, NULL, log_scale);
+        } else { /* svt_av1_quantize_fp_facade / svt_av1_highbd_quantize_fp_facade (full_loop.c:344-516): the fp rows, one function per log scale */
+            DECLARE_ALIGNED(16, int16_t, rfp[8]); DECLARE_ALIGNED(16, int16_t, qfp[8]);
+            for (int k = 0; k < 8; k++) { rfp[k] = qr->round_fp[k != 0]; qfp[k] = qr->quant_fp[k != 0]; }
+            if (hbd) svt_av1_highbd_quantize_fp_c(co, NP, zbin, rfp, qfp, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan, (int16_t)log_scale);
+            else if (log_scale == 0) svt_av1_quantize_fp_c(co, NP, zbin, rfp, qfp, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan);
+            else if (log_scale == 1) svt_av1_quantize_fp_32x32_c(co, NP, zbin, rfp, qfp, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan);
+            else svt_av1_quantize_fp_64x64_c(co, NP, zbin, rfp, qfp, qsh, q, dq, deq, &d->eob[j], so->scan, so->iscan);
+        }
         if (d->cul_level) d->cul_level[j] = svt_av1_compute_cul_level_c(so->scan, q, &d->eob[j]); /* the wrapper's return value, full_loop.c:1836 */
         uint64_t dist[DIST_CALC_TOTAL];
         svt_full_distortion_kernel32_bits(co, WP, dq, WP, dist, WP, HP);
@@ -495,7 +507,19 @@ int ref_rd_batch(const SvtHipRdBatchDesc *d) {
             for (int c = 0; c < W; c++)
                 p16[r * W + c] = hbd ? ((const uint16_t *)d->pred)[jb->pred_offset + (size_t)r * d->pred_stride + c]
                                      : ((const uint8_t *)d->pred)[jb->pred_offset + (size_t)r * d->pred_stride + c];
-        g_inv_sq[ts](dq, p16, W, r16, W, tt, bd);
+        if (ts <= 4) g_inv_sq[ts](dq, p16, W, r16, W, tt, bd);
+        else {
+            typedef void (*InvRect4)(const int32_t *, uint16_t *, int32_t, uint16_t *, int32_t, TxType, TxSize, int32_t);
+            typedef void (*InvRect)(const int32_t *, uint16_t *, int32_t, uint16_t *, int32_t, TxType, TxSize, int32_t, int32_t);
+            static const InvRect4 k4[19] = {[5] = svt_av1_inv_txfm2d_add_4x8_c, [6] = svt_av1_inv_txfm2d_add_8x4_c, [13] = svt_av1_inv_txfm2d_add_4x16_c,
+                                            [14] = svt_av1_inv_txfm2d_add_16x4_c};
+            static const InvRect  kr[19] = {[7] = svt_av1_inv_txfm2d_add_8x16_c, [8] = svt_av1_inv_txfm2d_add_16x8_c, [9] = svt_av1_inv_txfm2d_add_16x32_c,
+                                            [10] = svt_av1_inv_txfm2d_add_32x16_c, [11] = svt_av1_inv_txfm2d_add_32x64_c, [12] = svt_av1_inv_txfm2d_add_64x32_c,
+                                            [15] = svt_av1_inv_txfm2d_add_8x32_c, [16] = svt_av1_inv_txfm2d_add_32x8_c, [17] = svt_av1_inv_txfm2d_add_16x64_c,
+                                            [18] = svt_av1_inv_txfm2d_add_64x16_c};
+            if (k4[ts]) k4[ts](dq, p16, W, r16, W, tt, (TxSize)ts, bd);
+            else kr[ts](dq, p16, W, r16, W, tt, (TxSize)ts, W * H, bd);
+        }
         uint64_t sse;
         if (hbd) sse = svt_full_distortion_kernel16_bits((uint8_t *)((uint16_t *)d->src + jb->src_offset), 0, d->src_stride, (uint8_t *)r16, 0, W, W, H);
         else {

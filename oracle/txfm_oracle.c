@@ -4,7 +4,7 @@
  * the reference's svt_av1_transform_two_d_* / svt_av1_fwd_txfm2d_* / svt_av1_inv_txfm2d_add_* `_c` functions for
  * all 19 sizes x the types each allows in tests/test_dsp_oracle_vs_ref.py (where the reference build exists), and
  * through the RD chain's fixture tests/golden/rd_chain.npz (tests/test_rd_golden.py: outputs of the reference's `_c`
- * chain for the square sizes, which travel to the GPU box).
+ * chain for all 19 sizes, which travel to the GPU box).
  *
  * The reference spells every butterfly network out stage by stage.  Here the same flow graphs are expressed by
  * their structure: a DCT of size N is one add/sub butterfly, a DCT of size N/2 on the sums and an "odd part" on

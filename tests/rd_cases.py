@@ -1,10 +1,10 @@
 """Shared definition of the RD-chain fixture (tests/golden/rd_chain.npz): the cases oracle/gen_golden.py runs through the reference's own
-`_c` chain (residual -> svt_av1_fwd_txfm2d_* -> svt_aom_satd -> quantizer -> distortions -> svt_av1_inv_txfm2d_add_* -> SSE,
-oracle/ref_harness.c:ref_rd_batch) and that the tests run through the oracle (CPU) and svt_hip_rd_batch (GPU).  A case = one square
-transform size x bit depth with the "b" quantizer (what the harness chains; rectangular sizes, the fp quantizer, quantization matrices and the
-partial-frequency shapes are pinned function by function in tests/test_dsp_oracle_vs_ref.py, which needs the reference build) on a seeded
-192 x 128 plane pair; its jobs tile the planes and cycle through the transform types the size allows and three quantizer rows.  Kept per
-case: the per-block scalars in full and a CRC of every coefficient / reconstruction array (the fixture stays small)."""
+`_c` chain (residual -> svt_av1_fwd_txfm2d_* / svt_handle_transform* -> svt_aom_satd -> quantizer -> distortions -> svt_av1_inv_txfm2d_add_*
+-> SSE, oracle/ref_harness.c:ref_rd_batch) and that the tests run through the oracle (CPU) and svt_hip_rd_batch (GPU).  A case = one of the
+19 transform sizes x bit depth x quantizer ("b" / "fp") on a seeded 192 x 128 plane pair; its jobs tile the planes and cycle through the
+transform types the size allows and three quantizer rows.  (Quantization matrices and the partial-frequency shapes are pinned function by
+function in tests/test_dsp_oracle_vs_ref.py, which needs the reference build.)  Kept per case: the per-block scalars in full and a CRC of
+every coefficient / reconstruction array (the fixture stays small)."""
 import zlib
 
 import numpy as np
@@ -13,7 +13,7 @@ from svt_av1_psyex_amd import abi, rd
 from txfm_cases import valid_types
 
 W, H = 192, 128
-CASES = [(ts, bd, 0) for ts in range(5) for bd in (8, 10)]
+CASES = [(ts, bd, qk) for ts in range(19) for bd, qk in ((8, ts & 1), (10, 1 - (ts & 1)))] + [(ts, 10, 0) for ts in (4, 12, 18)] + [(ts, 8, 1) for ts in (4, 11, 17)]
 SCALARS = [name for name, _, _ in abi.RD_OUT_FIELDS]
 ARRAYS = ("coeff", "qcoeff", "dqcoeff", "recon")
 
