@@ -31,7 +31,8 @@ typedef struct SvtHipMv { int16_t row, col; } SvtHipMv; /* MV / FULLPEL_MV, Code
 typedef struct SvtHipMvCostParam {
     const SvtHipMv *ref_mv;
     SvtHipMv        full_ref_mv;
-    int             mv_cost_type;
+    uint8_t         mv_cost_type; /* MV_COST_TYPE is UENUM1BYTE (Codec/mcomp.h:29-36, definitions.h:268): ONE byte; the three bytes after it are
+                                   * padding that md_full_pel_search leaves uninitialised on its stack (product_coding_loop.c:2030-2049) */
     const int      *mvjcost;   /* [MV_JOINTS = 4] */
     const int      *mvcost[2]; /* row / column component costs, pointers to the CENTRE (index 0) of MV_VALS-entry tables */
     int             error_per_bit;

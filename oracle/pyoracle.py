@@ -184,3 +184,43 @@ def block_stats(oracle, src, ref, jobs, bit_depth, satd=True, psy_rd=None, facad
     return out
 
 
+
+
+# ---- bench.py's CPU baseline: the reference's kernels on native threads (oracle/ref_harness.c:ref_bench_rows) ----
+class RefBenchPicture(C.Structure):
+    _fields_ = [("cfg", C.c_void_p), ("desc", C.c_void_p), ("cur_planes", C.c_void_p), ("ref_planes", C.c_void_p), ("src10", C.c_void_p), ("pred10", C.c_void_p)]
+
+
+class RefBenchDesc(C.Structure):
+    _fields_ = [("n_pictures", C.c_uint32), ("pictures", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("row_start", C.c_uint32), ("n_rows", C.c_uint32),
+                ("quant_row", C.c_void_p), ("n_tx_sizes", C.c_uint32), ("tx_sizes", C.c_void_p), ("n_threads", C.c_int32), ("seconds", C.c_double),
+                ("items_done", C.c_uint64), ("elapsed", C.c_double), ("checksum", C.c_uint64)]
+
+
+def ref_bench_rows(pictures, width, height, row_start, n_rows, quant_rows, tx_sizes, n_threads, seconds, simd=True):
+    """pictures: list of (cfg, desc, cur HostPyramid, refs dict (list, idx) -> HostPyramid, src10 uint16 [H, W], pred10 uint16 [H, W]).
+    Runs ME (svt_aom_motion_estimation_b64 over the sample's b64 rows) + the RD chain at `tx_sizes` on `n_threads` pthreads for about
+    `seconds`; returns (Mpixels/s, items done, elapsed seconds, checksum).  One item = one b64 row = 64 x width luma pixels."""
+    r = load_ref()
+    r.ref_sizeof_bench.restype = C.c_size_t
+    assert r.ref_sizeof_bench(0) == C.sizeof(RefBenchDesc) and r.ref_sizeof_bench(1) == C.sizeof(RefBenchPicture)
+    r.ref_set_simd(1 if simd else 0)
+    r.ref_set_simd_rd(1 if simd else 0)
+    keep = []
+    arr = (RefBenchPicture * len(pictures))()
+    for i, (cfg, desc, cur, refs, src10, pred10) in enumerate(pictures):
+        cp, rp = cur.descs(), ref_plane_array(refs)
+        src10, pred10 = np.ascontiguousarray(src10, np.uint16), np.ascontiguousarray(pred10, np.uint16)
+        assert src10.shape == (height, width) and pred10.shape == (height, width)
+        keep += [cfg, desc, cp, rp, src10, pred10]
+        arr[i] = RefBenchPicture(C.addressof(cfg), C.addressof(desc), C.addressof(cp), C.addressof(rp), src10.ctypes.data, pred10.ctypes.data)
+    qr = np.ascontiguousarray(quant_rows)
+    ts = np.ascontiguousarray(tx_sizes, np.int32)
+    d = RefBenchDesc(n_pictures=len(pictures), pictures=C.addressof(arr), width=width, height=height, row_start=row_start, n_rows=n_rows, quant_row=qr.ctypes.data,
+                     n_tx_sizes=len(ts), tx_sizes=ts.ctypes.data, n_threads=n_threads, seconds=seconds)
+    rc = r.ref_bench_rows(C.byref(d))
+    r.ref_set_simd(0)
+    r.ref_set_simd_rd(0)
+    if rc != 0:
+        raise RuntimeError(f"ref_bench_rows failed: {rc}")
+    return d.items_done * 64 * width / d.elapsed / 1e6, int(d.items_done), float(d.elapsed), int(d.checksum)

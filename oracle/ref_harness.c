@@ -462,15 +462,29 @@ void ref_set_simd_rd(int use_simd) {
 #endif
 }
 
-int ref_rd_batch(const SvtHipRdBatchDesc *d) {
+/* working buffers of one thread of the chain: the largest transform block (64 x 64) */
+typedef struct RdScratch {
+    int16_t  *res;
+    int32_t  *co, *q, *dq;
+    uint16_t *p16, *r16;
+} RdScratch;
+static int rd_scratch_alloc(RdScratch *s) {
+    const size_t n = 64 * 64;
+    s->res = aligned_alloc(64, sizeof(int16_t) * n);
+    s->co = aligned_alloc(64, sizeof(int32_t) * n); s->q = aligned_alloc(64, sizeof(int32_t) * n); s->dq = aligned_alloc(64, sizeof(int32_t) * n);
+    s->p16 = aligned_alloc(64, sizeof(uint16_t) * n); s->r16 = aligned_alloc(64, sizeof(uint16_t) * n);
+    return !(s->res && s->co && s->q && s->dq && s->p16 && s->r16);
+}
+static void rd_scratch_free(RdScratch *s) { free(s->res); free(s->co); free(s->q); free(s->dq); free(s->p16); free(s->r16); }
+
+static int rd_batch_core(const SvtHipRdBatchDesc *d, const RdScratch *sc) {
     const int ts = d->tx_size;
-    if (!g_fwd[0]) ref_set_simd_rd(0);
     if (ts < 0 || ts > 18 || d->quant_kind > 1 || d->qmatrix) return 2; /* every size, "b" and "fp" quantizers, flat matrices, full transforms */
     const int W = tx_size_wide[ts], H = tx_size_high[ts], WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
     const int bd = d->bit_depth, hbd = bd != 8, log_scale = av1_get_tx_scale_tab[ts];
-    int16_t  *res = aligned_alloc(64, sizeof(int16_t) * W * H);
-    int32_t  *co = aligned_alloc(64, sizeof(int32_t) * W * H), *q = aligned_alloc(64, sizeof(int32_t) * W * H), *dq = aligned_alloc(64, sizeof(int32_t) * W * H);
-    uint16_t *p16 = aligned_alloc(64, sizeof(uint16_t) * W * H), *r16 = aligned_alloc(64, sizeof(uint16_t) * W * H);
+    int16_t  *res = sc->res;
+    int32_t  *co = sc->co, *q = sc->q, *dq = sc->dq;
+    uint16_t *p16 = sc->p16, *r16 = sc->r16;
     for (uint32_t j = 0; j < d->n_jobs; j++) {
         const SvtHipTxJob    *jb = &d->jobs[j];
         const SvtHipQuantRow *qr = &d->quant_rows[jb->quant_row];
@@ -538,8 +552,16 @@ int ref_rd_batch(const SvtHipRdBatchDesc *d) {
         if (d->qcoeff) memcpy(d->qcoeff + (size_t)j * NP, q, sizeof(int32_t) * NP);
         if (d->dqcoeff) memcpy(d->dqcoeff + (size_t)j * NP, dq, sizeof(int32_t) * NP);
     }
-    free(res); free(co); free(q); free(dq); free(p16); free(r16);
     return 0;
+}
+
+int ref_rd_batch(const SvtHipRdBatchDesc *d) {
+    if (!g_fwd[0]) ref_set_simd_rd(0);
+    RdScratch sc;
+    if (rd_scratch_alloc(&sc)) { rd_scratch_free(&sc); return 1; }
+    const int rc = rd_batch_core(d, &sc);
+    rd_scratch_free(&sc);
+    return rc;
 }
 
 /* =====================================================================================================================
@@ -625,3 +647,238 @@ void **ref_rtcd_slot(const char *name) {
 #undef SLOT
     return NULL;
 }
+
+/* =====================================================================================================================
+ * bench.py's CPU baseline, natively threaded: what the reference's ME threads and mode-decision threads do for the bench's
+ * work -- the b64 loop of svt_aom_motion_estimation_kernel (Codec/me_process.c:174-290) around svt_aom_motion_estimation_b64
+ * with the kernels ref_set_simd() installed, followed by the RD chain (rd_batch_core above, the kernels ref_set_simd_rd()
+ * installed) over the same b64 row at the three transform depths.  One work item = one b64 row of one picture; n_threads
+ * pthreads pull items from a shared counter (cyclically over the sample) for `seconds` (seconds <= 0: every item exactly once).  Everything a thread needs -- its
+ * MeContext, pcs, MeSbResults of one row, transform scratch, job lists, output arrays -- is created ONCE before the clock starts;
+ * the timed loop allocates nothing and shares only read-only planes (as the encoder's threads do).
+ * ===================================================================================================================== */
+#include <pthread.h>
+#include <stdatomic.h>
+#include <time.h>
+
+typedef struct RefBenchPicture {
+    const SvtHipMeConfig      *cfg;
+    const SvtHipMePictureDesc *desc;
+    const SvtHipPlaneDesc     *cur_planes;                /* [3] */
+    const SvtHipPlaneDesc     *ref_planes;                /* [SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS][3] */
+    const uint16_t            *src10, *pred10;            /* W x H 10-bit planes, stride = width */
+} RefBenchPicture;
+
+typedef struct RefBenchDesc {
+    uint32_t               n_pictures;
+    const RefBenchPicture *pictures;
+    uint32_t               width, height;                 /* luma size; the 10-bit planes have stride == width */
+    uint32_t               row_start, n_rows;             /* the sample: b64 rows [row_start, row_start + n_rows) of every picture */
+    const SvtHipQuantRow  *quant_row;
+    uint32_t               n_tx_sizes;
+    const int32_t         *tx_sizes;                      /* RD depths, e.g. {TX_64X64, TX_32X32, TX_16X16} */
+    int32_t                n_threads;
+    double                 seconds;
+    /* out */
+    uint64_t               items_done;
+    double                 elapsed;
+    uint64_t               checksum;                      /* keeps the work observable (sum of 64x64 distortions and eobs) */
+} RefBenchDesc;
+
+typedef struct BenchThread {
+    RefBenchDesc *d;
+    atomic_ullong *next;
+    volatile int  *stop;
+    /* ME state */
+    SequenceControlSet *scs; PictureParentControlSet *pcs; MeContext *m; MotionEstimationData *med;
+    MeSbResults *row_res;
+    uint32_t    *dist[6];
+    uint8_t     *flags[2];
+    EbPictureBufferDesc cur[3], refs[SVT_HIP_MAX_LISTS][SVT_HIP_MAX_REFS][3];
+    int          cur_pic;
+    /* RD state */
+    RdScratch    sc;
+    SvtHipTxJob *jobs;
+    uint16_t    *eob; uint32_t *satd; uint64_t *dc, *sse, *tqe;
+    uint64_t     done, checksum;
+    int          failed;
+} BenchThread;
+
+static void fill_desc(EbPictureBufferDesc *d, const SvtHipPlaneDesc *p) {
+    memset(d, 0, sizeof(*d));
+    d->buffer_y = (EbByte)p->buffer_y; d->stride_y = p->stride_y; d->org_x = p->org_x; d->org_y = p->org_y;
+    d->width = p->width; d->height = p->height; d->max_width = p->width; d->max_height = p->height;
+}
+
+static int bench_thread_init(BenchThread *t) {
+    const RefBenchDesc *d = t->d;
+    const SvtHipMePictureDesc *d0 = d->pictures[0].desc;
+    const uint32_t w64 = (d0->aligned_width + 63) / 64, h64 = (d0->aligned_height + 63) / 64, nb = w64 * h64;
+    const uint32_t n_pu = svt_hip_me_n_pu(d0->enable_me_16x16, d0->enable_me_8x8);
+    t->scs = calloc(1, sizeof(*t->scs)); t->pcs = calloc(1, sizeof(*t->pcs)); t->m = calloc(1, sizeof(*t->m)); t->med = calloc(1, sizeof(*t->med));
+    t->row_res = calloc(w64, sizeof(MeSbResults));
+    t->med->me_results = calloc(nb, sizeof(MeSbResults *));
+    t->pcs->b64_geom   = calloc(nb, sizeof(B64Geom));
+    if (!t->scs || !t->pcs || !t->m || !t->med || !t->row_res || !t->med->me_results || !t->pcs->b64_geom) return 1;
+    for (int k = 0; k < 6; k++) if (!(t->dist[k] = calloc(nb, sizeof(uint32_t)))) return 1;
+    for (int k = 0; k < 2; k++) if (!(t->flags[k] = calloc(nb, 1))) return 1;
+    for (uint32_t x = 0; x < w64; x++) {
+        MeSbResults *r = &t->row_res[x];
+        r->total_me_candidate_index = calloc(n_pu, 1);
+        r->me_mv_array              = calloc((size_t)n_pu * SVT_HIP_MAX_REFS * SVT_HIP_MAX_LISTS, sizeof(MvCandidate));
+        r->me_candidate_array       = calloc((size_t)n_pu * 32, sizeof(MeCandidate));
+        if (!r->total_me_candidate_index || !r->me_mv_array || !r->me_candidate_array) return 1;
+    }
+    for (uint32_t b = 0; b < nb; b++) { /* every row of the picture lands in the thread's one row of result storage */
+        t->med->me_results[b] = &t->row_res[b % w64];
+        B64Geom *g = &t->pcs->b64_geom[b];
+        g->org_x = (uint16_t)((b % w64) * 64); g->org_y = (uint16_t)((b / w64) * 64);
+        g->width  = (uint8_t)((d0->aligned_width - g->org_x) < 64 ? d0->aligned_width - g->org_x : 64);
+        g->height = (uint8_t)((d0->aligned_height - g->org_y) < 64 ? d0->aligned_height - g->org_y : 64);
+    }
+    t->scs->b64_size = 64;
+    t->pcs->scs = t->scs; t->pcs->pa_me_data = t->med;
+    t->pcs->me_64x64_distortion = t->dist[0]; t->pcs->me_32x32_distortion = t->dist[1]; t->pcs->me_16x16_distortion = t->dist[2];
+    t->pcs->me_8x8_distortion = t->dist[3]; t->pcs->rc_me_distortion = t->dist[4]; t->pcs->me_8x8_cost_variance = t->dist[5];
+    t->pcs->stationary_block_present_sb = t->flags[0]; t->pcs->rc_me_allow_gm = t->flags[1];
+    t->cur_pic = -1;
+    if (rd_scratch_alloc(&t->sc)) return 1;
+    const size_t max_jobs = (size_t)((d->width + 3) / 4) * 16; /* 4x4 blocks of one b64 row: more than any depth needs */
+    t->jobs = calloc(max_jobs, sizeof(SvtHipTxJob));
+    t->eob = calloc(max_jobs, sizeof(uint16_t)); t->satd = calloc(max_jobs, sizeof(uint32_t)); t->dc = calloc(max_jobs * 2, sizeof(uint64_t));
+    t->sse = calloc(max_jobs, sizeof(uint64_t)); t->tqe = calloc(max_jobs, sizeof(uint64_t));
+    return !(t->jobs && t->eob && t->satd && t->dc && t->sse && t->tqe);
+}
+
+static void bench_thread_free(BenchThread *t) {
+    if (t->row_res && t->d) {
+        const uint32_t w64 = (t->d->pictures[0].desc->aligned_width + 63) / 64;
+        for (uint32_t x = 0; x < w64; x++) { free(t->row_res[x].total_me_candidate_index); free(t->row_res[x].me_mv_array); free(t->row_res[x].me_candidate_array); }
+    }
+    if (t->med) free(t->med->me_results);
+    if (t->pcs) free(t->pcs->b64_geom);
+    for (int k = 0; k < 6; k++) free(t->dist[k]);
+    for (int k = 0; k < 2; k++) free(t->flags[k]);
+    free(t->row_res); free(t->med); free(t->m); free(t->pcs); free(t->scs);
+    rd_scratch_free(&t->sc);
+    free(t->jobs); free(t->eob); free(t->satd); free(t->dc); free(t->sse); free(t->tqe);
+}
+
+/* what the ME kernel does when it takes a new picture (me_process.c:140-172: signal derivation and picture pointers) */
+static void bench_set_picture(BenchThread *t, int pi) {
+    const RefBenchPicture     *p    = &t->d->pictures[pi];
+    const SvtHipMePictureDesc *desc = p->desc;
+    SequenceControlSet *scs = t->scs; PictureParentControlSet *pcs = t->pcs; MeContext *m = t->m;
+    scs->input_resolution = (EbInputResolution)desc->input_resolution;
+    scs->mrp_ctrls.only_l_bwd = desc->only_l_bwd;
+    pcs->picture_number = desc->picture_number; pcs->aligned_width = desc->aligned_width; pcs->aligned_height = desc->aligned_height;
+    pcs->hierarchical_levels = desc->hierarchical_levels; pcs->temporal_layer_index = desc->temporal_layer_index;
+    pcs->similar_brightness_refs = desc->similar_brightness_refs; pcs->enable_me_8x8 = desc->enable_me_8x8; pcs->enable_me_16x16 = desc->enable_me_16x16;
+    pcs->max_number_of_pus_per_sb = desc->max_number_of_pus_per_sb;
+    pcs->gm_ctrls.enabled = desc->gm_enabled; pcs->gm_ctrls.use_distance_based_active_th = desc->gm_use_distance_based_active_th;
+    t->med->max_cand = desc->max_cand; t->med->max_refs = desc->max_refs; t->med->max_l0 = desc->max_l0;
+    ctx_from_cfg(p->cfg, m);
+    m->me_type = p->cfg->me_type == 1 ? ME_MCTF : ME_OPEN_LOOP;
+    m->tf_me_exit_th = (uint16_t)desc->tf_me_exit_th;
+    m->num_of_list_to_search = desc->num_of_list_to_search;
+    m->num_of_ref_pic_to_search[0] = desc->num_of_ref_pic_to_search[0]; m->num_of_ref_pic_to_search[1] = desc->num_of_ref_pic_to_search[1];
+    m->temporal_layer_index = desc->temporal_layer_index; m->is_ref = desc->is_ref;
+    for (int l = 0; l < 3; l++) fill_desc(&t->cur[l], &p->cur_planes[l]);
+    for (int li = 0; li < desc->num_of_list_to_search; li++)
+        for (int ri = 0; ri < desc->num_of_ref_pic_to_search[li]; ri++) {
+            for (int l = 0; l < 3; l++) fill_desc(&t->refs[li][ri][l], &p->ref_planes[(li * SVT_HIP_MAX_REFS + ri) * 3 + l]);
+            m->me_ds_ref_array[li][ri].sixteenth_picture_ptr = &t->refs[li][ri][0];
+            m->me_ds_ref_array[li][ri].quarter_picture_ptr   = &t->refs[li][ri][1];
+            m->me_ds_ref_array[li][ri].picture_ptr           = &t->refs[li][ri][2];
+            m->me_ds_ref_array[li][ri].picture_number        = desc->ref_picture_number[li][ri];
+        }
+    t->cur_pic = pi;
+}
+
+static void bench_item(BenchThread *t, int pi, uint32_t by) {
+    const RefBenchDesc *d = t->d;
+    if (t->cur_pic != pi) bench_set_picture(t, pi);
+    const RefBenchPicture *p = &d->pictures[pi];
+    MeContext *m = t->m;
+    const uint32_t w64 = (p->desc->aligned_width + 63) / 64;
+    EbPictureBufferDesc *cur = t->cur;
+    for (uint32_t bx = 0; bx < w64; bx++) { /* me_process.c:183-214 */
+        const uint32_t b = bx + by * w64, ox = bx * 64, oy = by * 64;
+        m->b64_src_ptr    = &cur[2].buffer_y[(cur[2].org_y + oy) * cur[2].stride_y + cur[2].org_x + ox];
+        m->b64_src_stride = cur[2].stride_y;
+        m->quarter_b64_buffer = &cur[1].buffer_y[(cur[1].org_y + (oy >> 1)) * cur[1].stride_y + cur[1].org_x + (ox >> 1)];
+        m->quarter_b64_buffer_stride = cur[1].stride_y;
+        m->sixteenth_b64_buffer = &cur[0].buffer_y[(cur[0].org_y + (oy >> 2)) * cur[0].stride_y + cur[0].org_x + (ox >> 2)];
+        m->sixteenth_b64_buffer_stride = cur[0].stride_y;
+        svt_aom_motion_estimation_b64(t->pcs, b, ox, oy, m, &cur[2]);
+        t->checksum += t->dist[0][b];
+    }
+    /* the RD chain over the row's transform blocks, depth by depth */
+    const uint32_t y_lo = by * 64, y_hi = (y_lo + 64) < d->height ? y_lo + 64 : d->height;
+    for (uint32_t k = 0; k < d->n_tx_sizes; k++) {
+        const int ts = d->tx_sizes[k], bw = tx_size_wide[ts], bh = tx_size_high[ts];
+        uint32_t  n = 0;
+        for (uint32_t y = y_lo; y + bh <= y_hi; y += bh)
+            for (uint32_t x = 0; x + bw <= d->width; x += bw) {
+                SvtHipTxJob *j = &t->jobs[n++];
+                memset(j, 0, sizeof(*j));
+                j->src_offset = j->pred_offset = y * d->width + x;
+            }
+        SvtHipRdBatchDesc rd;
+        memset(&rd, 0, sizeof(rd));
+        rd.bit_depth = 10; rd.quant_kind = 0; rd.tx_size = (uint8_t)ts; rd.n_jobs = n; rd.src_stride = rd.pred_stride = d->width;
+        rd.src = p->src10; rd.pred = p->pred10; rd.jobs = t->jobs; rd.quant_rows = d->quant_row; rd.n_quant_rows = 1;
+        rd.eob = t->eob; rd.satd = t->satd; rd.dist_coeff = t->dc; rd.sse = t->sse; rd.three_quad_energy = t->tqe;
+        if (rd_batch_core(&rd, &t->sc)) { t->failed = 1; return; }
+        for (uint32_t j = 0; j < n; j++) t->checksum += t->eob[j];
+    }
+}
+
+static void *bench_thread_main(void *arg) {
+    BenchThread        *t = arg;
+    const RefBenchDesc *d = t->d;
+    const uint64_t      n_items = (uint64_t)d->n_pictures * d->n_rows;
+    const int           once = d->seconds <= 0; /* every item exactly once: a deterministic checksum for the tests */
+    while (!*t->stop && !t->failed) {
+        uint64_t i = atomic_fetch_add(t->next, 1);
+        if (once && i >= n_items) break;
+        i %= n_items;
+        bench_item(t, (int)(i / d->n_rows), d->row_start + (uint32_t)(i % d->n_rows));
+        t->done++;
+    }
+    return NULL;
+}
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+/* Runs the sample on d->n_threads threads for about d->seconds; fills items_done / elapsed / checksum.  The kernels are the ones
+ * ref_set_simd / ref_set_simd_rd installed last.  0 on success. */
+int ref_bench_rows(RefBenchDesc *d) {
+    if (!d || !d->n_pictures || !d->n_rows || d->n_threads < 1 || d->n_tx_sizes > 8) return 2;
+    ref_set_simd(g_simd);
+    if (!g_fwd[0]) ref_set_simd_rd(0);
+    const int    nt = d->n_threads;
+    BenchThread *th = calloc(nt, sizeof(*th));
+    pthread_t   *id = calloc(nt, sizeof(*id));
+    atomic_ullong next = 0;
+    volatile int  stop = 0;
+    int rc = (!th || !id);
+    for (int i = 0; i < nt && !rc; i++) { th[i].d = d; th[i].next = &next; th[i].stop = &stop; rc = bench_thread_init(&th[i]); }
+    if (!rc) { /* one untimed item per thread: pages the planes in, warms the caches */
+        for (int i = 0; i < nt; i++) { bench_item(&th[i], i % d->n_pictures, d->row_start + (i / d->n_pictures) % d->n_rows); th[i].checksum = 0; }
+        int started = 0;
+        const double t0 = now_s();
+        for (int i = 0; i < nt; i++, started++) if (pthread_create(&id[i], NULL, bench_thread_main, &th[i])) { rc = 3; break; }
+        struct timespec nap = {0, 2000000};
+        while (!rc && now_s() - t0 < d->seconds) nanosleep(&nap, NULL);
+        if (d->seconds > 0 || rc) stop = 1;
+        for (int i = 0; i < started; i++) pthread_join(id[i], NULL);
+        d->elapsed = now_s() - t0; /* up to the last thread's last item */
+        d->items_done = 0; d->checksum = 0;
+        for (int i = 0; i < nt; i++) { d->items_done += th[i].done; d->checksum += th[i].checksum; rc |= th[i].failed ? 4 : 0; }
+    }
+    for (int i = 0; th && i < nt; i++) bench_thread_free(&th[i]);
+    free(th); free(id);
+    return rc;
+}
+size_t ref_sizeof_bench(int what) { return what == 0 ? sizeof(RefBenchDesc) : sizeof(RefBenchPicture); }

@@ -197,7 +197,7 @@ class Mv(C.Structure):
 
 
 class MvCostParam(C.Structure):  # MV_COST_PARAMS, Codec/mcomp.h:37-48
-    _fields_ = [("ref_mv", C.POINTER(Mv)), ("full_ref_mv", Mv), ("mv_cost_type", C.c_int), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2),
+    _fields_ = [("ref_mv", C.POINTER(Mv)), ("full_ref_mv", Mv), ("mv_cost_type", C.c_uint8), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2),
                 ("error_per_bit", C.c_int), ("early_exit_th", C.c_int), ("sad_per_bit", C.c_int)]
 
 
