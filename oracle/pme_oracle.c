@@ -70,3 +70,11 @@ int orc_pme_sad_batch(const SvtHipPmeBatchDesc *d) {
     return 0;
 }
 size_t orc_sizeof_pme(int what) { return what == 0 ? sizeof(SvtHipPmeJob) : what == 1 ? sizeof(SvtHipPmeBatchDesc) : sizeof(SvtHipMvCostParam); }
+#include <stddef.h>
+void orc_mv_cost_param_layout(size_t out[9]) {
+    out[0] = sizeof(SvtHipMvCostParam);
+    out[1] = offsetof(SvtHipMvCostParam, ref_mv); out[2] = offsetof(SvtHipMvCostParam, full_ref_mv); out[3] = offsetof(SvtHipMvCostParam, mv_cost_type);
+    out[4] = offsetof(SvtHipMvCostParam, mvjcost); out[5] = offsetof(SvtHipMvCostParam, mvcost); out[6] = offsetof(SvtHipMvCostParam, error_per_bit);
+    out[7] = offsetof(SvtHipMvCostParam, early_exit_th); out[8] = offsetof(SvtHipMvCostParam, sad_per_bit);
+    { SvtHipMvCostParam p; out[3] |= (size_t)sizeof(p.mv_cost_type) << 16; }
+}

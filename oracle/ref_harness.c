@@ -882,3 +882,14 @@ int ref_bench_rows(RefBenchDesc *d) {
     return rc;
 }
 size_t ref_sizeof_bench(int what) { return what == 0 ? sizeof(RefBenchDesc) : sizeof(RefBenchPicture); }
+
+/* layout of the reference's MV_COST_PARAMS (Codec/mcomp.h:37-48): sizeof, then offsetof of each field in declaration order */
+#include <stddef.h>
+#include "mcomp.h"
+void ref_mv_cost_param_layout(size_t out[9]) {
+    out[0] = sizeof(MV_COST_PARAMS);
+    out[1] = offsetof(MV_COST_PARAMS, ref_mv); out[2] = offsetof(MV_COST_PARAMS, full_ref_mv); out[3] = offsetof(MV_COST_PARAMS, mv_cost_type);
+    out[4] = offsetof(MV_COST_PARAMS, mvjcost); out[5] = offsetof(MV_COST_PARAMS, mvcost); out[6] = offsetof(MV_COST_PARAMS, error_per_bit);
+    out[7] = offsetof(MV_COST_PARAMS, early_exit_th); out[8] = offsetof(MV_COST_PARAMS, sad_per_bit);
+    { MV_COST_PARAMS p; out[3] |= (size_t)sizeof(p.mv_cost_type) << 16; } /* width of the enum field in the high half */
+}

@@ -53,17 +53,21 @@ def run_oracle(oracle, src, ref, jobs, cost_type, epb, tables):
     return cost, mv
 
 
-def run_ref(ref_lib, src, ref, jobs, cost_type, epb, tables):
-    """the reference's svt_pme_sad_loop_kernel_c, call by call"""
+def run_ref(ref_lib, src, ref, jobs, cost_type, epb, tables, garbage=None, fn="svt_pme_sad_loop_kernel_c"):
+    """the reference's svt_pme_sad_loop_kernel_c (or another function with its prototype), call by call; garbage: byte the parameter struct
+    is filled with before its fields are assigned (the padding bytes keep it)"""
     jc, tr, tc = tables
     n = len(jobs)
     cost, mv = np.zeros(n, np.uint32), np.zeros((n, 2), np.int16)
     for i, j in enumerate(jobs):
         rmv = abi.Mv(int(j["ref_mv"][0]), int(j["ref_mv"][1]))
-        p = abi.MvCostParam(ref_mv=C.pointer(rmv), mv_cost_type=cost_type, mvjcost=jc.ctypes.data, error_per_bit=epb)
+        p = abi.MvCostParam()
+        if garbage is not None:
+            C.memset(C.byref(p), garbage, C.sizeof(p))
+        p.ref_mv, p.mv_cost_type, p.mvjcost, p.error_per_bit = C.pointer(rmv), cost_type, jc.ctypes.data, epb
         p.mvcost[0], p.mvcost[1] = tr.ctypes.data + 4 * MV_CENTRE, tc.ctypes.data + 4 * MV_CENTRE
         bc, bx, by = C.c_uint32(int(j["best_cost"])), C.c_int16(int(j["best_mvx"])), C.c_int16(int(j["best_mvy"]))
-        ref_lib.svt_pme_sad_loop_kernel_c(C.byref(p), C.c_void_p(src.ctypes.data + int(j["src_offset"])), C.c_uint32(src.shape[1]),
+        getattr(ref_lib, fn)(C.byref(p), C.c_void_p(src.ctypes.data + int(j["src_offset"])), C.c_uint32(src.shape[1]),
                                           C.c_void_p(ref.ctypes.data + int(j["ref_offset"])), C.c_uint32(ref.shape[1]), C.c_uint32(int(j["height"])), C.c_uint32(int(j["width"])),
                                           C.byref(bc), C.byref(bx), C.byref(by), C.c_int16(int(j["start_x"])), C.c_int16(int(j["start_y"])), C.c_int16(int(j["sa_w"])),
                                           C.c_int16(int(j["sa_h"])), C.c_int16(int(j["step"])), C.c_int16(int(j["mvx"])), C.c_int16(int(j["mvy"])))

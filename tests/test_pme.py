@@ -41,6 +41,33 @@ def test_struct_layouts(oracle):
     assert oracle.orc_sizeof_pme(2) == C.sizeof(abi.MvCostParam)
 
 
+def test_mv_cost_param_layout_is_the_references(oracle, ref):
+    """SvtHipMvCostParam == MV_COST_PARAMS field by field: offsets, size, and the ONE-byte mv_cost_type (UENUM1BYTE); ctypes mirror too"""
+    a, b = (C.c_size_t * 9)(), (C.c_size_t * 9)()
+    ref.ref_mv_cost_param_layout(a)
+    oracle.orc_mv_cost_param_layout(b)
+    assert list(a) == list(b)
+    assert a[3] >> 16 == 1
+    m = abi.MvCostParam
+    assert [C.sizeof(m), m.ref_mv.offset, m.full_ref_mv.offset, m.mv_cost_type.offset | (m.mv_cost_type.size << 16), m.mvjcost.offset, m.mvcost.offset,
+            m.error_per_bit.offset, m.early_exit_th.offset, m.sad_per_bit.offset] == list(a)
+
+
+@pytest.mark.parametrize("cost_type", [0, 1, 3, 4, 5])
+def test_garbage_padding_after_mv_cost_type(oracle, ref, cost_type):
+    """md_full_pel_search builds MV_COST_PARAMS on its stack field by field (product_coding_loop.c:2030-2049): the three padding bytes behind
+    the one-byte mv_cost_type are garbage.  The oracle must read the type exactly as the reference does."""
+    rng = np.random.default_rng(300 + cost_type)
+    tables = cost_tables(rng)
+    src, rp = planes(rng, "noise")
+    jobs = random_jobs(rng, W, H, 40)
+    a = run_ref(ref, src, rp, jobs, cost_type, 20542, tables)
+    b = run_ref(ref, src, rp, jobs, cost_type, 20542, tables, garbage=0xFF)
+    c = run_ref(oracle, src, rp, jobs, cost_type, 20542, tables, garbage=0x5A, fn="orc_pme_sad_loop_kernel")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cost_type", [0, 3, 4, 5])
 def test_hip_batch_matches_oracle(hip_ctx, oracle, cost_type):
@@ -69,7 +96,9 @@ def test_leaf_pme_sad_loop_kernel(hip_ctx, oracle):
         want = run_oracle(oracle, src, rp, jobs, 0, 20542, (jc, tr, tc))
         for i, j in enumerate(jobs):
             rmv = abi.Mv(int(j["ref_mv"][0]), int(j["ref_mv"][1]))
-            p = abi.MvCostParam(ref_mv=C.pointer(rmv), mv_cost_type=0, mvjcost=jc.ctypes.data, error_per_bit=20542)
+            p = abi.MvCostParam()
+            C.memset(C.byref(p), 0xA5, C.sizeof(p))  # the caller's stack garbage, padding bytes included
+            p.ref_mv, p.mv_cost_type, p.mvjcost, p.error_per_bit = C.pointer(rmv), 0, jc.ctypes.data, 20542
             p.mvcost[0], p.mvcost[1] = tr.ctypes.data + 4 * MV_CENTRE, tc.ctypes.data + 4 * MV_CENTRE
             bc, bx, by = C.c_uint32(int(j["best_cost"])), C.c_int16(int(j["best_mvx"])), C.c_int16(int(j["best_mvy"]))
             L.svt_pme_sad_loop_kernel_hip(C.byref(p), C.c_void_p(src.ctypes.data + int(j["src_offset"])), C.c_uint32(W), C.c_void_p(rp.ctypes.data + int(j["ref_offset"])),
