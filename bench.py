@@ -33,7 +33,43 @@ import statistics
 import sys
 import time
 
-import numpy as np
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end leg and the other kernels' timings")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks_if_needed():
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher (no WORLD_SIZE in the environment): this process -- which has
+    not imported torch, loaded libsvthip.so or touched the GPU in any way yet -- starts the N ranks itself through
+    torch.distributed.run as a CHILD process (one rank per GPU, rendezvous on 127.0.0.1) and exits with its status.  Never an exec:
+    replacing a process that has initialised the GPU is forbidden on this pool, and a child is just as good."""
+    if __name__ != "__main__" or "WORLD_SIZE" in os.environ:
+        return
+    a = parse_args()
+    if a.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as so:  # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {a.gpus} without a launcher: starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+spawn_ranks_if_needed()
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -564,17 +600,11 @@ def other_kernels(ctx, wl, ext):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end leg and the other kernels' timings")
-    a = ap.parse_args()
+    a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world:
+    if a.gpus != world:  # the launcher's world size wins (the parent of spawn_ranks_if_needed starts exactly --gpus ranks)
         log(f"--gpus {a.gpus} but WORLD_SIZE {world}: running with world size {world}")
     # SVT_BENCH_REHEARSAL=1: every rank uses GPU 0 and the exchange goes through gloo on host copies -- a functional dress
     # rehearsal of the N > 1 code path on a one-GPU box (band sharding, job lists, buffers, timing reductions); its `value`
@@ -633,12 +663,14 @@ def main():
     # per kernel family: the median over the pass's launches (one disturbed launch -- a clock ramp, a neighbour on the PCIe switch -- would
     # otherwise move a mean of six by a multiple)
     kms = {k: float(np.median([s.elapsed_time(e) for s, e in v])) for k, v in ev.items()}
-    if rehearsal and world > 1:
+    gather_check = None
+    if world > 1:
         while (step_no[0] - 1) % N_SETS != 0:
             run(1)
         barrier()
-    if rehearsal and world > 1 and rank == 0:
-        # the gathered buffers of all ranks, unpacked, must equal a whole-picture run (two pictures with different band rotations)
+    if world > 1 and rank == 0:
+        # outside the timed region, on the real RCCL path as in the rehearsal: the gathered buffers of all ranks, unpacked, must equal a
+        # whole-picture run of this rank (two pictures with different band rotations)
         k = wl.last_k0
         for pi in (0, 5):
             pic = PICS[pi]
@@ -647,8 +679,14 @@ def main():
             whole = ctx.me_picture(wl.cfgs[pic], whole_desc, wl.sets[0].pics[pic[0]], wl.sets[0].refs(pic), search_level=False)
             merged = wl.layout.unpack(xch.out[k].cpu().numpy(), pi)
             bad = [kk for kk in merged if not np.array_equal(np.asarray(whole[kk]).reshape(merged[kk].shape), merged[kk])]
-            log(f"rehearsal: gathered results of picture {pi} " + ("MATCH a whole-picture run" if not bad else f"DIFFER in {bad}"))
+            log(f"{'rehearsal' if rehearsal else xch.kind}: gathered results of picture {pi} " + ("MATCH a whole-picture run" if not bad else f"DIFFER in {bad}"))
             assert not bad, bad
+        gather_check = "gathered results of pictures 0 and 5 (all ranks' bands, unpacked) == a whole-picture run on rank 0"
+    rccl_ranks = None
+    if xch and xch.comm:
+        n = C.c_int(0)
+        ctx.check(api.lib().svt_hip_comm_count(xch.comm, C.byref(n)), "svt_hip_comm_count")
+        rccl_ranks = int(n.value)
     # ---- end-to-end leg: the PCIe copies inside the step (4 new input pictures in, the gathered results out) ----
     e2e = None
     if not a.no_extras:
@@ -756,6 +794,9 @@ def main():
             "rd_roofline": rd_roof,
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
         }
+        if xch:
+            out["exchange"] = {"kind": xch.kind, "rccl_ranks": rccl_ranks, "bytes_per_step_all_ranks": int(sum(wl.layout.rank_bytes)), "uniform_bands": bool(wl.layout.uniform),
+                               "check": gather_check}
         if e2e:
             out["end_to_end"] = e2e
         if extras:

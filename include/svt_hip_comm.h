@@ -31,6 +31,8 @@ int  svt_hip_comm_create(SvtHipContext *ctx, const uint8_t id[SVT_HIP_COMM_ID_BY
 void svt_hip_comm_destroy(SvtHipComm *comm);
 int  svt_hip_comm_rank(const SvtHipComm *comm);
 int  svt_hip_comm_world(const SvtHipComm *comm);
+/* The rank count RCCL reports for the communicator (ncclCommCount): recorded next to multi-GPU measurements. */
+int  svt_hip_comm_count(SvtHipComm *comm, int *ranks);
 
 /* Enqueue the exchange of result set `slot` (0 / 1): `send_dev` = this rank's compact result buffer (device, bytes_per_rank bytes, written by
  * work already enqueued on the context stream, e.g. svt_hip_me_pictures_async), `recv_dev` = world * bytes_per_rank bytes, rank r's buffer

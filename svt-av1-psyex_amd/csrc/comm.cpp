@@ -17,6 +17,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId)    GetUniqueId;
     decltype(&ncclCommInitRank)   CommInitRank;
     decltype(&ncclCommDestroy)    CommDestroy;
+    decltype(&ncclCommCount)      CommCount;
     decltype(&ncclAllGather)      AllGather;
     decltype(&ncclBroadcast)      Broadcast;
     decltype(&ncclGroupStart)     GroupStart;
@@ -40,7 +41,7 @@ int load_rccl(SvtHipContext *ctx) {
 #define SYM(field, name)                                                                                         \
     g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));                                   \
     if (!g_rccl.field) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_DEVICE, "librccl.so lacks %s", name);
-    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount") SYM(AllGather, "ncclAllGather")
     SYM(Broadcast, "ncclBroadcast") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     g_rccl_ready = true;
@@ -133,15 +134,17 @@ static int exchange_end(SvtHipComm *c, int slot) {
 }
 
 int svt_hip_me_results_all_gather(SvtHipComm *c, int slot, const void *send_dev, void *recv_dev, size_t bytes_per_rank) {
+    if (!c || slot < 0 || slot >= SVT_HIP_COMM_SLOTS) return SVT_HIP_ERR_BAD_PARAM;
+    if (!send_dev || !recv_dev) return svt_hip_fail(c->ctx, SVT_HIP_ERR_BAD_PARAM, "all-gather: null buffer"); // before any stream is touched
     if (int rc = exchange_begin(c, slot)) return rc;
-    if (!send_dev || !recv_dev) return svt_hip_fail(c->ctx, SVT_HIP_ERR_BAD_PARAM, "all-gather: null buffer");
     if (bytes_per_rank) RCCL_CHECK(c->ctx, g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, c->comm, c->stream));
     return exchange_end(c, slot);
 }
 
 int svt_hip_me_results_all_gather_v(SvtHipComm *c, int slot, const void *send_dev, void *recv_dev, const size_t *offsets, const size_t *bytes) {
+    if (!c || slot < 0 || slot >= SVT_HIP_COMM_SLOTS) return SVT_HIP_ERR_BAD_PARAM;
+    if (!send_dev || !recv_dev || !offsets || !bytes) return svt_hip_fail(c->ctx, SVT_HIP_ERR_BAD_PARAM, "all-gather-v: null argument"); // before any stream is touched
     if (int rc = exchange_begin(c, slot)) return rc;
-    if (!send_dev || !recv_dev || !offsets || !bytes) return svt_hip_fail(c->ctx, SVT_HIP_ERR_BAD_PARAM, "all-gather-v: null argument");
     // one broadcast per rank, fused into one group: rank r's `bytes[r]` live bytes land at recv + offsets[r] on every rank
     RCCL_CHECK(c->ctx, g_rccl.GroupStart());
     for (int r = 0; r < c->world; r++)
@@ -166,6 +169,13 @@ int svt_hip_comm_stream_wait(SvtHipComm *c, int slot) {
 int svt_hip_comm_sync(SvtHipComm *c) {
     if (!c) return SVT_HIP_ERR_BAD_PARAM;
     SVT_HIP_CHECK(c->ctx, hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
+
+// the number of ranks RCCL itself reports for the communicator (ncclCommCount): what a caller records next to a multi-GPU measurement
+int svt_hip_comm_count(SvtHipComm *c, int *ranks) {
+    if (!c || !ranks) return SVT_HIP_ERR_BAD_PARAM;
+    RCCL_CHECK(c->ctx, g_rccl.CommCount(c->comm, ranks));
     return SVT_HIP_OK;
 }
 

@@ -47,9 +47,29 @@ class BandLayout:
         self.bytes_per_b64 = sum(dt.itemsize * c for _, dt, c in self.fields)
         self.bands = [[band(h64, r, world, rotation(p, h64, world)) for p in range(n_pictures)] for r in range(world)]
         self.rank_rows = [sum(r1 - r0 for r0, r1 in self.bands[r]) for r in range(world)]
-        self.rank_bytes = [rows * w64 * self.bytes_per_b64 for rows in self.rank_rows]
+        # every field's band starts on a 16-byte boundary of the rank's buffer (the kernel stores 32-bit fields with dword stores:
+        # a band of u8 entries whose length is not a multiple of 4 must not push the next field off its alignment)
+        self._foff = [[self._layout_picture(r, p) for p in range(n_pictures)] for r in range(world)]
+        off = [0] * world
+        for r in range(world):
+            for p in range(n_pictures):
+                fo, size = self._foff[r][p]
+                self._foff[r][p] = {n: (o + off[r], per) for n, (o, per) in fo.items()}
+                off[r] += size
+        self.rank_bytes = off
         self.nbytes = max(self.rank_bytes)
         self.uniform = len(set(self.rank_bytes)) == 1  # a plain all-gather moves live bytes only
+
+    ALIGN = 16
+
+    def _layout_picture(self, rank, picture):
+        r0, r1 = self.bands[rank][picture]
+        nb = (r1 - r0) * self.w64
+        off, out = 0, {}
+        for n, dt, c in self.fields:
+            out[n] = (off, dt.itemsize * c)
+            off += -(-(nb * dt.itemsize * c) // self.ALIGN) * self.ALIGN
+        return out, off
 
     def band(self, picture, rank):
         """[row0, row1) of `rank` in the `picture`-th picture of the exchange (may be empty when world > h64)."""
@@ -61,14 +81,7 @@ class BandLayout:
 
     def field_offsets(self, picture, rank):
         """name -> (byte offset of the field's first band row in `rank`'s buffer, bytes per b64)."""
-        off = sum(r1 - r0 for r0, r1 in self.bands[rank][:picture]) * self.w64 * self.bytes_per_b64
-        r0, r1 = self.bands[rank][picture]
-        nb = (r1 - r0) * self.w64
-        out = {}
-        for n, dt, c in self.fields:
-            out[n] = (off, dt.itemsize * c)
-            off += nb * dt.itemsize * c
-        return out
+        return self._foff[rank][picture]
 
     def results_struct(self, base_ptr, picture, rank):
         """abi.MeResults whose pointers are biased so that absolute b64 indices of `rank`'s band land in its compact buffer."""

@@ -21,6 +21,9 @@ def test_all_gather_world_one(hip_ctx):
     hip_ctx.check(L.svt_hip_comm_create(hip_ctx._h, ident, 0, 1, C.byref(comm)), "svt_hip_comm_create")
     try:
         assert L.svt_hip_comm_rank(comm) == 0 and L.svt_hip_comm_world(comm) == 1
+        n_ranks = C.c_int(-1)
+        hip_ctx.check(L.svt_hip_comm_count(comm, C.byref(n_ranks)), "svt_hip_comm_count")  # what RCCL itself says (ncclCommCount)
+        assert n_ranks.value == 1
         ext = torch.cuda.ExternalStream(hip_ctx.stream)
         n = 1 << 20
         for slot, form in ((0, "plain"), (1, "v"), (0, "plain")):
@@ -44,5 +47,9 @@ def test_all_gather_world_one(hip_ctx):
             else:
                 assert np.array_equal(a[:n - 100], b[32:32 + n - 100]) and not b[:32].any() and not b[32 + n - 100:].any()
         assert L.svt_hip_me_results_all_gather(comm, 5, None, None, C.c_size_t(0)) == 2  # bad slot
+        # arguments are validated before any stream is touched: a null buffer leaves the slot's events alone
+        assert L.svt_hip_me_results_all_gather_v(comm, 0, None, None, None, None) == 2
+        hip_ctx.check(L.svt_hip_comm_stream_wait(comm, 0), "svt_hip_comm_stream_wait")
+        hip_ctx.sync()
     finally:
         L.svt_hip_comm_destroy(comm)

@@ -88,7 +88,13 @@ def test_layout_holds_live_rows_only_and_survives_empty_bands():
     """The per-rank buffers hold the live rows only (no padding to the tallest band); with more ranks than b64 rows some bands are
     empty (a caller then skips the launch: b64_row_count == 0 means "all rows" in the C-ABI)."""
     lay = shard.BandLayout(60, 34, 8, 85, 2, 3, n_pictures=16)
-    assert lay.uniform and lay.rank_rows == [68] * 8 and lay.nbytes == 68 * 60 * lay.bytes_per_b64
+    live = 68 * 60 * lay.bytes_per_b64
+    assert lay.uniform and lay.rank_rows == [68] * 8 and live <= lay.nbytes < live + 16 * 16 * len(lay.fields)  # at most one 16-byte pad per field band
+    for r in range(8):  # every field band starts on a 16-byte boundary (32-bit fields are stored with dword stores)
+        for p in range(16):
+            assert all(off % 16 == 0 for off, _ in lay.field_offsets(p, r).values())
+    odd = shard.BandLayout(30, 17, 4, 85, 2, 3, n_pictures=3)  # 1080p: 30 blocks per row, bands of 4 / 5 rows -> u8 bands that are no multiple of 4
+    assert all(off % 16 == 0 for r in range(4) for p in range(3) for off, _ in odd.field_offsets(p, r).values())
     lay = shard.BandLayout(60, 34, 3, 85, 2, 3, n_pictures=16)
     assert sum(lay.rank_rows) == 16 * 34 and max(lay.rank_rows) - min(lay.rank_rows) <= 1
     small = shard.BandLayout(6, 5, 8, 85, 2, 3, n_pictures=2)  # 5 rows on 8 ranks
