@@ -182,6 +182,14 @@ int   svt_hip_context_sync(SvtHipContext *ctx);
  * mode-decision kernels of earlier pictures on another context's stream beside the ME launch -- as the reference runs its ME and
  * mode-decision processes side by side -- lowers it so that both find LDS and registers on every CU. */
 int   svt_hip_context_set_me_waves_per_cu(SvtHipContext *ctx, uint32_t waves);
+/* The dense pre-pass of the ME launches of this context (on by default; the environment variable SVT_HIP_ME_DENSE=0 turns it off at
+ * context creation): the pre-HME strips (prehme_core, Codec/motion_estimation.c:1568-1666) and the HME level-0 regions (hme_level_0,
+ * :820-920) of every block -- searches whose windows depend on the block position and the picture distance only -- are made by a kernel of
+ * their own ahead of the per-block kernel, which takes their results instead of searching.  Results are identical either way. */
+int   svt_hip_context_set_me_dense(SvtHipContext *ctx, int on);
+/* Diagnostics: out[0] = searches the per-block kernel took from the pre-pass, out[1] = searches it made itself although the pre-pass was
+ * on (edge blocks, configurations the pre-pass does not cover), since the last call; waits for the context's streams. */
+int   svt_hip_me_dense_counters(SvtHipContext *ctx, unsigned long long out[2]);
 
 /* ---- preset derivation (host only) ---- */
 /* Restates svt_aom_sig_deriv_me + svt_aom_sig_deriv_multi_processes' HME flags (enc_mode_config.c:138-833,1632-1642). */

@@ -110,6 +110,16 @@ class Context:
             lib().svt_hip_context_destroy(self._h)
             self._h = C.c_void_p()
 
+    def set_me_dense(self, on):
+        """the dense pre-HME / HME level-0 pre-pass of the ME launches (svt_hip_context_set_me_dense); results are identical either way"""
+        self.check(lib().svt_hip_context_set_me_dense(self._h, 1 if on else 0), "svt_hip_context_set_me_dense")
+
+    def me_dense_counters(self):
+        """(searches taken from the dense pre-pass, searches the per-block kernel made itself) since the last call"""
+        v = (C.c_ulonglong * 2)()
+        self.check(lib().svt_hip_me_dense_counters(self._h, v), "svt_hip_me_dense_counters")
+        return int(v[0]), int(v[1])
+
     # --- pictures -----------------------------------------------------------------------------------
     def upload(self, host_pyramid, device_pyramid=True):
         """HostPyramid -> HBM-resident pyramid.  device_pyramid=True builds 1/4 and 1/16 on the GPU."""

@@ -111,15 +111,40 @@ struct MeKernelParams {
 // picture's band-local b64 raster index; eight queues (one per XCD) each own a contiguous range of global indices.
 #define SVT_HIP_ME_MAX_PICTURES 16
 #define SVT_HIP_ME_HEADER_BYTES 256 /* sizeof(MeBatchHeader) rounded up: the parameter blocks follow at this offset */
+// Dense pre-pass (me_dense.inl): one slot per (global job index, searched (list, reference) pair, kind)
+#define SVT_HIP_ME_DENSE_KINDS 6   /* two pre-HME strips + 2 x 2 level-0 regions */
+#define SVT_HIP_ME_COUNTER_WORD 112 /* u32 index into a lane's queue_head block: two u64 counters (dense slots taken / not found) */
+struct MeDenseSlot {
+    unsigned long long key;  // sad << 32 | y << 16 | x (search indices), ~0 when no position was evaluated / not computed
+    uint32_t           org;  // (uint16)ox | (uint16)oy << 16: displacement of search index (0, 0)
+    uint32_t           size; // sa_w | sa_h << 16
+};
+// One (picture, searched reference, kind) of a launch's dense pre-pass: units = band rows x dy segments x lane chunks
+struct MeDenseEntry {
+    uint32_t unit_base;         // first unit of the entry in the launch's unit numbering
+    uint16_t pic;
+    uint8_t  li, ri, k, kind;   // k: row of (li, ri) among the picture's searched pairs
+    uint16_t noct, nos;         // octets of the unclipped search width; octet slots per block (a lane walks the octets slot, slot + nos, ...)
+    uint16_t n_chunk, n_seg;    // chunks of 64 lanes per block row; dy segments
+    uint16_t seg_len, n_rows;   // search rows per segment; b64 rows of the picture's band
+    uint32_t pad;
+};
+#define SVT_HIP_ME_DENSE_MAX_ENTRIES (SVT_HIP_ME_MAX_PICTURES * SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS * SVT_HIP_ME_DENSE_KINDS)
+
 struct MeBatchHeader {
     uint32_t  n_pictures, n_slot; // n_slot: the largest number of (list, reference) pairs a picture of the launch searches
     uint32_t  job_base[SVT_HIP_ME_MAX_PICTURES + 1];
     uint32_t  queue_begin[SVT_HIP_ME_QUEUES + 1];
     uint32_t  cshift, pad; // 1: the source views in LDS keep their even rows only (every search of the launch is row-subsampled)
     uint32_t *queue_head; // SVT_HIP_ME_QUEUES counters, zeroed before launch
+    MeDenseSlot *dense;   // results of the dense pre-pass, [job_base[n_pictures]][n_slot][SVT_HIP_ME_DENSE_KINDS]; null: no pre-pass
+    uint32_t  n_dense_entries, n_dense_units;
 };
 #ifdef __cplusplus
 static_assert(sizeof(MeBatchHeader) <= SVT_HIP_ME_HEADER_BYTES, "header size");
 #endif
+// A lane's parameter block (device copy and the pinned ring): header, SVT_HIP_ME_MAX_PICTURES parameter blocks, the dense entry table
+#define SVT_HIP_ME_ENTRIES_OFFSET (SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * SVT_HIP_ME_MAX_PICTURES)
+#define SVT_HIP_ME_PARAM_BYTES (SVT_HIP_ME_ENTRIES_OFFSET + sizeof(MeDenseEntry) * SVT_HIP_ME_DENSE_MAX_ENTRIES)
 
 #endif

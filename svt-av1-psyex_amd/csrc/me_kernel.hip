@@ -80,9 +80,11 @@ struct Req { // one svt_sad_loop_kernel call (compute_sad_c.c:58-101)
     uint32_t       stride;
     int16_t        sa_w, sa_h;
     uint8_t        bw, bh, rs, level; // block width, effective rows, plane rows per block row, source view
-    uint8_t        skip_even, pad0;
+    uint8_t        skip_even, done; // done: the result is already in St.req_key[] (taken from the dense pre-pass): no tile is planned for it
     int16_t        pad1;
 };
+
+struct SearchGeo { int ox, oy, sa_w, sa_h; }; // origin (displacement of search index (0, 0)) and size of a search after clipping
 
 // One tile of a stage's searches: a rectangle of a request's search area whose reference window fits the arena.  The tiles of a stage are
 // planned once, lane-parallel (plan_tiles), into St.tile[]; the load / store / evaluation passes of a round read their entries back as
@@ -153,15 +155,16 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
 // p_sb_best_mv of the (list, reference) pairs the launch's pictures search: n_slot = the largest count among them), the window
 // arena.  When every picture of the launch sub-samples both the HME and the integer search (SUB_SAD_SEARCH: every other row),
 // the source views keep their even rows only (cshift = 1): row r of a view lives at row r >> cshift.
-struct LdsLayout { uint32_t src16, src32, src64, bsad, bmv, win, total; };
-__host__ __device__ constexpr LdsLayout lds_layout(int n_slot, int cshift) {
+struct LdsLayout { uint32_t src16, src32, src64, bsad, bmv, dense, win, total; };
+__host__ __device__ constexpr LdsLayout lds_layout(int n_slot, int cshift, int dense = 1) {
     LdsLayout l = {};
     l.src16 = (uint32_t)((sizeof(St) + 15) & ~(size_t)15);
     l.src32 = l.src16 + (uint32_t)((16 >> cshift) * kSrc16Pitch);
     l.src64 = l.src32 + (uint32_t)((32 >> cshift) * kSrc32Pitch);
     l.bsad  = l.src64 + (uint32_t)((64 >> cshift) * kSrc64Pitch);
     l.bmv   = l.bsad + (uint32_t)n_slot * 85 * 4;
-    l.win   = (l.bmv + (uint32_t)n_slot * 85 * 4 + 15) & ~15u;
+    l.dense = (l.bmv + (uint32_t)n_slot * 85 * 4 + 15) & ~15u; // the block's slots of the dense pre-pass: n_slot x SVT_HIP_ME_DENSE_KINDS x 16 bytes
+    l.win   = l.dense + (dense ? (uint32_t)n_slot * SVT_HIP_ME_DENSE_KINDS * 16u : 0u);
     l.total = l.win + (uint32_t)kWinBytes;
     return l;
 }
@@ -193,15 +196,16 @@ __device__ __forceinline__ u64 wave_sum64(u64 v) {
     return v;
 }
 
-__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // svt_aom_get_scaled_picture_distance, motion_estimation.c:1239-1243
-__device__ __forceinline__ uint32_t scaled_distance(uint32_t dist) { return (dist * 5) / 8 + ((dist % 8) ? 1 : 0); }
+__host__ __device__ __forceinline__ uint32_t scaled_distance(uint32_t dist) { return (dist * 5) / 8 + ((dist % 8) ? 1 : 0); }
 
-__device__ __forceinline__ uint32_t ref_distance(CParams &p, int li, int ri) {
+// (P = the kernel's constant-address-space view of the parameter block, or the launcher's host copy)
+template <class P> __host__ __device__ __forceinline__ uint32_t ref_distance(P &p, int li, int ri) {
     long long d = (long long)p.desc.picture_number - (long long)p.desc.ref_picture_number[li][ri];
     return (uint16_t)(int16_t)(d < 0 ? -d : d);
 }
@@ -469,7 +473,9 @@ __device__ __forceinline__ int plan_tiles(St &st, int nreq, int t0) {
     Req r = {};
     if (lane < nreq) {
         r = st.req[lane];
-        if (r.sa_w > 0 && r.sa_h > 0) {
+        if (r.done) {
+            // nothing to evaluate
+        } else if (r.sa_w > 0 && r.sa_h > 0) {
             tw = r.sa_w; th = r.sa_h;
             while (th > 1 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
             while (tw > 8 && tile_bytes(r, tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
@@ -756,7 +762,7 @@ __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM)
     bool ok = true;
     if (lane < nreq) {
         const Req &r = st.req[lane];
-        ok = r.sa_w == w && r.sa_h == h && r.bw == bw && r.bh == bh && r.rs == rs && r.level == level && !r.skip_even;
+        ok = r.sa_w == w && r.sa_h == h && r.bw == bw && r.bh == bh && r.rs == rs && r.level == level && !r.skip_even && !r.done;
     }
     if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
     const int ng = (w + 7) >> 3, per = ng * h, Q = per * nreq; // octet items of one slice
@@ -796,6 +802,25 @@ __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM)
     return true;
 }
 
+// A result of the dense pre-pass (me_dense.inl): the pre-HME strips and the HME level-0 regions of every block are searched ahead of the
+// per-block kernel by a kernel of their own -- their windows depend on the block's position and the picture distance only, never on
+// earlier results -- which leaves one 16-byte slot per (block, searched reference, kind): the search's key and the geometry it was made
+// for.  A stage that is about to push such a search takes the key when the geometry is the one it wants (always, by construction: both
+// sides call prehme_geometry / hme_level_geometry; the compare is what makes a slot the pre-pass did not fill -- an edge block, a
+// configuration it does not cover -- fall back to the search itself).
+constexpr int kDenseKinds = SVT_HIP_ME_DENSE_KINDS; // 0, 1: pre-HME strips; 2 + 2 h + w: level-0 regions
+__device__ __forceinline__ uint32_t dense_pack(int a, int b) { return (uint32_t)(uint16_t)a | ((uint32_t)(uint16_t)b << 16); }
+__device__ __forceinline__ void dense_take(St &st, const MeDenseSlot *dl, int idx, int req, const SearchGeo &g, uint32_t &n_hit, uint32_t &n_miss) {
+    if (!dl) return;
+    const MeDenseSlot s = dl[idx];
+    if (s.org == dense_pack(g.ox, g.oy) && s.size == dense_pack(g.sa_w, g.sa_h)) {
+        st.req[req].done = 1;
+        st.req_key[req]  = s.key == ~0ull ? ((0xffffffull << 32) | 0xffffffffull) : s.key; // no position evaluated
+        n_hit++;
+    } else
+        n_miss++;
+}
+
 // slot < 0: append (serial pushes by lane 0); otherwise the caller owns st.req[slot] and sets st.nreq itself (lane-parallel pushes)
 __device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t stride, int sa_w, int sa_h, int bw, int bh, int rs,
                                          int level, int skip, int slot = -1) {
@@ -809,6 +834,7 @@ __device__ __forceinline__ void push_req(St &st, const uint8_t *win, uint32_t st
     r.rs        = (uint8_t)rs;
     r.level     = (uint8_t)level;
     r.skip_even = (uint8_t)(skip && bw == 16 && bh <= 16);
+    r.done      = 0;
 }
 
 // The svt_sad_loop_kernel call made by the HME levels and pre-HME (e.g. motion_estimation.c:891-909)
@@ -1019,15 +1045,16 @@ __device__ void set_hme_all(St &st, CParams &p, int lvl, int li, int ri, int x, 
 
 // get_hme_l0_search_area, motion_estimation.c:1800-1868
 // Works on a copy of the block's total level-0 area (the reference divides its context's copy in place and restores it after
-// each reference, motion_estimation.c:1948-1953,2031-2034: every reference starts from the same base)
-__device__ void hme_l0_search_area(const St &cst, CParams &p, int li, int ri, uint32_t dist, int &sa_w, int &sa_h) {
-    struct { SvtHipSearchAreaMinMax hme_l0_sa; } st = {cst.hme_l0_sa};
-    const int16_t (*hx0)[4][2][2] = cst.hx[0], (*hy0)[4][2][2] = cst.hy[0];
+// each reference, motion_estimation.c:1948-1953,2031-2034: every reference starts from the same base).  (mvx, mvy) = list 0 / reference 0's
+// level-0 result of region (0, 0), read only when both reduce_hme_l0_sr thresholds are set.
+template <class P> __host__ __device__ __forceinline__ void hme_l0_area(P &p, int li, int ri, uint32_t dist, int mvx, int mvy, int &sa_w, int &sa_h) {
     auto &c = p.cfg;
+    struct { SvtHipSearchAreaMinMax hme_l0_sa; } st;
+    st.hme_l0_sa.sa_min.width = (uint16_t)c.hme_l0_sa.sa_min.width; st.hme_l0_sa.sa_min.height = (uint16_t)c.hme_l0_sa.sa_min.height;
+    st.hme_l0_sa.sa_max.width = (uint16_t)c.hme_l0_sa.sa_max.width; st.hme_l0_sa.sa_max.height = (uint16_t)c.hme_l0_sa.sa_max.height;
     if (c.enable_me_sr_adjustment && c.distance_based_hme_resizing) {
         int is_hor = 1, is_ver = 1, is_still = 0;
         if (c.reduce_hme_l0_sr_th_min && c.reduce_hme_l0_sr_th_max && (li || ri)) {
-            const int mvx = hx0[0][0][0][0], mvy = hy0[0][0][0][0];
             is_ver   = iabs(mvx) < c.reduce_hme_l0_sr_th_min && iabs(mvy) > c.reduce_hme_l0_sr_th_max;
             is_hor   = iabs(mvx) > c.reduce_hme_l0_sr_th_max && iabs(mvy) < c.reduce_hme_l0_sr_th_min;
             is_still = iabs(mvx) < c.reduce_hme_l0_sr_th_min * 3 && iabs(mvy) < c.reduce_hme_l0_sr_th_min * 3;
@@ -1047,12 +1074,34 @@ __device__ void hme_l0_search_area(const St &cst, CParams &p, int li, int ri, ui
     sa_w        = w;
     sa_h        = h;
 }
+__device__ void hme_l0_search_area(const St &cst, CParams &p, int li, int ri, uint32_t dist, int &sa_w, int &sa_h) {
+    hme_l0_area(p, li, ri, dist, cst.hx[0][0][0][0][0], cst.hy[0][0][0][0][0], sa_w, sa_h);
+}
 
-struct HmeGeom { int16_t ox, oy; };
+// ---- search geometry shared by the per-block kernel and the dense pre-pass (me_dense.inl): origin (displacement of search index (0, 0)
+// from the co-located block) and size of a search after the reference's clipping to the padded plane ----
+// pre-HME strip `sri` of (list, reference): prehme_b64 (motion_estimation.c:1722-1796) sizes it from the picture distance, prehme_core
+// (:1568-1666) centres and clips it; org_x / org_y = the block's full-resolution origin
+template <class P> __host__ __device__ __forceinline__ void prehme_size(P &p, int li, int ri, int sri, int &sa_w, int &sa_h) {
+    auto &c = p.cfg;
+    const uint32_t f = scaled_distance(ref_distance(p, li, ri));
+    sa_w = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.width * f), c.prehme_sa_cfg[sri].sa_max.width);
+    sa_h = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.height * f), c.prehme_sa_cfg[sri].sa_max.height);
+}
+__device__ __forceinline__ SearchGeo prehme_geometry(CParams &p, int li, int ri, int sri, uint32_t org_x, uint32_t org_y) {
+    int sa_w, sa_h;
+    prehme_size(p, li, ri, sri, sa_w, sa_h);
+    CPlane &rp = p.ref[li][ri].lvl[0];
+    const int ox16 = (int16_t)org_x >> 2, oy16 = (int16_t)org_y >> 2;
+    int ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
+    clip_axis(ox16, ox, sa_w, rp.org_x - 1, rp.width);
+    clip_axis(oy16, oy, sa_h, rp.org_y - 1, rp.height);
+    SearchGeo g = {ox, oy, sa_w, sa_h};
+    return g;
+}
 
-// hme_level_0/1/2 geometry (motion_estimation.c:820-1113): pushes the search and returns its origin
-__device__ HmeGeom push_hme_level(St &st, CParams &p, int level, CPlane &rp, int org_x, int org_y, int bw, int bh,
-                                  int sa_w, int sa_h, int cx, int cy, int sr_w, int sr_h, int slot = -1) {
+// hme_level_0/1/2 geometry (motion_estimation.c:820-1113); org_x / org_y = the block's origin on the level's plane
+__device__ __forceinline__ SearchGeo hme_level_geometry(CParams &p, int level, CPlane &rp, int org_x, int org_y, int sa_w, int sa_h, int cx, int cy, int sr_w, int sr_h) {
     sa_w = (int16_t)((sa_w + 7) & ~7);
     int pad_w, pad_h, ox, oy;
     if (level == 2) { pad_w = pad_h = 63; } else { pad_w = rp.org_x - 1; pad_h = rp.org_y - 1; }
@@ -1066,8 +1115,18 @@ __device__ HmeGeom push_hme_level(St &st, CParams &p, int level, CPlane &rp, int
     clip_axis(org_x, ox, sa_w, pad_w, rp.width);
     sa_w = (sa_w < 8) ? sa_w : (sa_w & ~7);
     clip_axis(org_y, oy, sa_h, pad_h, rp.height);
-    push_hme_req(st, p, level, rp, org_x, org_y, bw, bh, ox, oy, sa_w, sa_h, 0, slot);
-    HmeGeom g = {(int16_t)ox, (int16_t)oy};
+    SearchGeo g = {ox, oy, sa_w, sa_h};
+    return g;
+}
+
+struct HmeGeom { int16_t ox, oy; };
+
+// hme_level_0/1/2: pushes the search and returns its origin
+__device__ HmeGeom push_hme_level(St &st, CParams &p, int level, CPlane &rp, int org_x, int org_y, int bw, int bh,
+                                  int sa_w, int sa_h, int cx, int cy, int sr_w, int sr_h, int slot = -1) {
+    const SearchGeo sg = hme_level_geometry(p, level, rp, org_x, org_y, sa_w, sa_h, cx, cy, sr_w, sr_h);
+    push_hme_req(st, p, level, rp, org_x, org_y, bw, bh, sg.ox, sg.oy, sg.sa_w, sg.sa_h, 0, slot);
+    HmeGeom g = {(int16_t)sg.ox, (int16_t)sg.oy};
     return g;
 }
 
@@ -1104,9 +1163,12 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
     const int tid = threadIdx.x; // the lane: a workgroup is one wave
     // MeContext.p_sb_best_sad / p_sb_best_mv rows of the (list, reference) pairs in use, behind the fixed part of the LDS slice
     const int       cshift = (int)hdr.cshift;
-    const LdsLayout lay    = lds_layout((int)hdr.n_slot, cshift);
+    const bool      has_dense = hdr.dense != nullptr; // uniform
+    const LdsLayout lay    = lds_layout((int)hdr.n_slot, cshift, has_dense ? 1 : 0);
     uint32_t *const bsad = reinterpret_cast<uint32_t *>(g_lds + lay.bsad);
     uint32_t *const bmv  = reinterpret_cast<uint32_t *>(g_lds + lay.bmv);
+    const MeDenseSlot *const dense_lds = has_dense ? reinterpret_cast<const MeDenseSlot *>(g_lds + lay.dense) : nullptr;
+    uint32_t n_hit = 0, n_miss = 0; // searches taken from / not found in the dense pre-pass (per lane; summed when the wave retires)
     Shared sh = {st, lay.src64, lay.src32, lay.src16, lay.win, cshift};
 
     // XCD-aware work pull: queue q holds a contiguous band of b64 rows; start with this XCD's own band
@@ -1176,6 +1238,8 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 st.performed_phme[li][ri][sri] = 0;
             }
         }
+        if (has_dense && tid < n_rows * kDenseKinds) // this block's slots of the dense pre-pass (read by the pre-HME / level-0 stages)
+            reinterpret_cast<uint4 *>(g_lds + lay.dense)[tid] = reinterpret_cast<const uint4 *>(hdr.dense)[((size_t)gjob * hdr.n_slot) * kDenseKinds + tid];
         // init_zz_sad (motion_estimation.c:2382-2437) rides on the set-up: while a lane holds a 16-byte piece of the source block it fetches the
         // same piece of every searched reference and adds up the zero-MV SAD of the even rows (get_zz_sad, :1667-1689) -- no staging, no
         // search rounds for single positions.  Sums in zz_sum[k], k = the searched (list, reference) pairs in the reference's loop order.
@@ -1265,7 +1329,6 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                     for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
                         st.ph_req[li][ri][0] = st.ph_req[li][ri][1] = 0;
                         if (!searched(p, li)) continue;
-                        const uint32_t f = scaled_distance(ref_distance(p, li, ri));
                         for (int sri = 0; sri < 2; sri++) {
                             PreHme &ph = st.prehme[li][ri][sri];
                             // check_prehme_early_exit (:1693-1720)
@@ -1277,16 +1340,14 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                                 }
                             }
                             if (!st.do_ref[li][ri]) { ph.col = ph.row = 0; ph.sad = 0xFFFFFFFFu; continue; }
-                            int sa_w = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.width * f), c.prehme_sa_cfg[sri].sa_max.width);
-                            int sa_h = (int16_t)(uint16_t)imin((int)(c.prehme_sa_cfg[sri].sa_min.height * f), c.prehme_sa_cfg[sri].sa_max.height);
                             // prehme_core (:1568-1666)
                             CPlane &rp = p.ref[li][ri].lvl[0];
                             const int ox16 = (int16_t)st.org_x >> 2, oy16 = (int16_t)st.org_y >> 2;
-                            int ox = -(int16_t)(sa_w >> 1), oy = -(int16_t)(sa_h >> 1);
-                            clip_axis(ox16, ox, sa_w, rp.org_x - 1, rp.width);
-                            clip_axis(oy16, oy, sa_h, rp.org_y - 1, rp.height);
-                            push_hme_req(st, p, 0, rp, ox16, oy16, (int)st.b64_w >> 2, (int)st.b64_h >> 2, ox, oy, sa_w, sa_h, c.prehme_skip_search_line);
+                            const SearchGeo sg = prehme_geometry(p, li, ri, sri, st.org_x, st.org_y);
+                            const int ox = sg.ox, oy = sg.oy;
+                            push_hme_req(st, p, 0, rp, ox16, oy16, (int)st.b64_w >> 2, (int)st.b64_h >> 2, ox, oy, sg.sa_w, sg.sa_h, c.prehme_skip_search_line);
                             st.ph_req[li][ri][sri] = (uint8_t)st.nreq;
+                            dense_take(st, dense_lds, (((li ? r0n : 0) + ri) * kDenseKinds + sri), st.nreq - 1, sg, n_hit, n_miss);
                             ph.col = (int16_t)ox; ph.row = (int16_t)oy; // search origin until the result is folded in
                             st.performed_phme[li][ri][sri] = 1;
                         }
@@ -1378,6 +1439,8 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                                                      (int)st.b64_h >> 2, sa_w, sa_h, 0, 0, w, h, slot);
                     st.hx[0][li][ri][w][h] = g.ox; st.hy[0][li][ri][w][h] = g.oy;
                     if (h == 0 && w == 0) st.l0_req[li][ri] = (uint8_t)(slot + 1);
+                    const SearchGeo sg = {g.ox, g.oy, st.req[slot].sa_w, st.req[slot].sa_h};
+                    dense_take(st, dense_lds, (((li ? r0n : 0) + ri) * kDenseKinds + 2 + h * 2 + w), slot, sg, n_hit, n_miss);
                 }
                 if (tid == 0) st.nreq = __popcll(mask);
             }
@@ -1920,12 +1983,21 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         PROF(16);
     }
     PROF_FLUSH(hdr.queue_head + 16);
+    if (has_dense) { // counters of the context's diagnostics entry (svt_hip_me_dense_counters)
+        const uint32_t h = wave_sum_u32(n_hit), m = wave_sum_u32(n_miss);
+        if (tid == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(hdr.queue_head + SVT_HIP_ME_COUNTER_WORD), (unsigned long long)h);
+            atomicAdd(reinterpret_cast<unsigned long long *>(hdr.queue_head + SVT_HIP_ME_COUNTER_WORD) + 1, (unsigned long long)m);
+        }
+    }
 }
 
 #undef BEST_SAD
 #undef BEST_MV
 
-size_t svt_hip_me_kernel_lds_bytes(void) { return lds_layout(SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS, 0).total + SVT_HIP_ME_PROFILE_LDS; }
+#include "me_dense.inl"
+
+size_t svt_hip_me_kernel_lds_bytes(void) { return lds_layout(SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS, 0, 1).total + SVT_HIP_ME_PROFILE_LDS; }
 
 #include "svt_hip_internal.h"
 
@@ -1953,6 +2025,25 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     for (int q = 0; q <= SVT_HIP_ME_QUEUES; q++) hdr.queue_begin[q] = (uint32_t)(((uint64_t)total * q) / SVT_HIP_ME_QUEUES);
     hdr.queue_head = lane->queue_head;
     SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->queue_head, 0, SVT_HIP_ME_QUEUES * sizeof(uint32_t), lane->stream));
+    // the dense pre-pass: entries, the slot buffer (one slot per job, searched reference and kind; 0xFF = "not filled")
+    static thread_local MeDenseEntry entries[SVT_HIP_ME_DENSE_MAX_ENTRIES];
+    uint32_t n_entries = 0, n_units = 0;
+    if (ctx->me_dense) n_entries = dense_plan(params, n_jobs, n_pictures, entries, &n_units);
+    if (n_units) {
+        const size_t need = (size_t)total * hdr.n_slot * SVT_HIP_ME_DENSE_KINDS * sizeof(MeDenseSlot);
+        if (need > lane->dense_bytes) {
+            if (lane->dense) {
+                SVT_HIP_CHECK(ctx, hipStreamSynchronize(lane->stream)); // earlier launches of this lane may still read the old buffer
+                hipFree(lane->dense);
+                lane->dense = nullptr; lane->dense_bytes = 0;
+            }
+            if (hipMalloc(&lane->dense, need) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "hipMalloc(%zu) failed (dense ME results)", need);
+            lane->dense_bytes = need;
+        }
+        SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->dense, 0xFF, need, lane->stream));
+        hdr.dense = static_cast<MeDenseSlot *>(lane->dense);
+        hdr.n_dense_entries = n_entries; hdr.n_dense_units = n_units;
+    }
     if (!ctx->me_attr_set) { // per context = per device; racing first calls set the same value
         SVT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(svt_hip_me_b64_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)svt_hip_me_kernel_lds_bytes()));
@@ -1960,7 +2051,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     }
     // persistent waves: as many per CU as the LDS slices (the window arena + the launch's best_sad / best_mv rows) and the register
     // budget of the launch bounds keep resident
-    const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift).total + SVT_HIP_ME_PROFILE_LDS + 127) & ~(size_t)127;
+    const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift, hdr.dense ? 1 : 0).total + SVT_HIP_ME_PROFILE_LDS + 127) & ~(size_t)127;
     uint32_t per_cu = (uint32_t)((160u * 1024u) / lds);
     if (per_cu > 4u * SVT_HIP_ME_WAVES_PER_SIMD) per_cu = 4u * SVT_HIP_ME_WAVES_PER_SIMD;
     if (ctx->me_waves_per_cu && per_cu > ctx->me_waves_per_cu) per_cu = ctx->me_waves_per_cu; // the caller leaves room for kernels of another stream
@@ -1972,11 +2063,45 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     uint8_t *host = lane->params_host[slot], *dev = lane->params_dev;
     memcpy(host, &hdr, sizeof(hdr));
     memcpy(host + SVT_HIP_ME_HEADER_BYTES, params, sizeof(MeKernelParams) * n_pictures);
-    SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * n_pictures, hipMemcpyHostToDevice, lane->stream));
+    size_t block_bytes = SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * n_pictures;
+    if (n_units) { // the entry table travels in the same block, behind the parameter blocks' full extent
+        memcpy(host + SVT_HIP_ME_ENTRIES_OFFSET, entries, sizeof(MeDenseEntry) * n_entries);
+        block_bytes = SVT_HIP_ME_ENTRIES_OFFSET + sizeof(MeDenseEntry) * n_entries;
+    }
+    SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, block_bytes, hipMemcpyHostToDevice, lane->stream));
     SVT_HIP_CHECK(ctx, hipEventRecord(lane->params_copied[slot], lane->stream));
+    if (n_units) {
+        hipLaunchKernelGGL(svt_hip_me_dense_kernel, dim3(n_units), dim3(64), 0, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
+                           reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES), reinterpret_cast<const MeDenseEntry *>(dev + SVT_HIP_ME_ENTRIES_OFFSET));
+        SVT_HIP_CHECK(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(64), lds, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
                        reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES));
     SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_context_set_me_dense(SvtHipContext *ctx, int on) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    ctx->me_dense = on != 0;
+    return SVT_HIP_OK;
+}
+
+// Diagnostics: searches the per-block kernel took from the dense pre-pass / pushed searches it found no slot for, summed over the lanes
+// since the last call (the call waits for the lanes' streams).
+extern "C" int svt_hip_me_dense_counters(SvtHipContext *ctx, unsigned long long out[2]) {
+    if (!ctx || !out) return SVT_HIP_ERR_BAD_PARAM;
+    out[0] = out[1] = 0;
+    hipSetDevice(ctx->device);
+    for (int i = 0; i < SVT_HIP_LANES; i++) {
+        SvtHipLane &l = ctx->lane[i];
+        if (!l.ready) continue;
+        unsigned long long v[2];
+        SVT_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
+        SVT_HIP_CHECK(ctx, hipMemcpy(v, l.queue_head + SVT_HIP_ME_COUNTER_WORD, sizeof(v), hipMemcpyDeviceToHost));
+        SVT_HIP_CHECK(ctx, hipMemset(l.queue_head + SVT_HIP_ME_COUNTER_WORD, 0, sizeof(v)));
+        out[0] += v[0]; out[1] += v[1];
+    }
     return SVT_HIP_OK;
 }
 

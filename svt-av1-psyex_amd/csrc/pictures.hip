@@ -122,6 +122,7 @@ int svt_hip_context_create(SvtHipContext **out, int device) {
     if (!ctx) return SVT_HIP_ERR_NO_MEMORY;
     ctx->device  = device;
     ctx->num_cus = prop.multiProcessorCount;
+    { const char *e = getenv("SVT_HIP_ME_DENSE"); ctx->me_dense = !(e && e[0] == '0'); }
     // lane 0 (the asynchronous entries' stream) and this device's transform tables exist from the start; the borrowed
     // lanes are made when a synchronous entry first needs one
     if (svt_hip_lane_setup(ctx, &ctx->lane[0], true) != SVT_HIP_OK || svt_hip_rd_tables_init(ctx) != SVT_HIP_OK) {
@@ -141,6 +142,7 @@ void svt_hip_context_destroy(SvtHipContext *ctx) {
         SvtHipLane &l = ctx->lane[i];
         if (l.stream) hipStreamSynchronize(l.stream);
         if (l.scratch) hipFree(l.scratch);
+        if (l.dense) hipFree(l.dense);
         if (l.queue_head) hipFree(l.queue_head);
         if (l.params_dev) hipFree(l.params_dev);
         for (int k = 0; k < SVT_HIP_PARAM_RING; k++) {
@@ -272,14 +274,18 @@ char *svt_hip_err_buf(void) {
 
 int svt_hip_lane_setup(SvtHipContext *ctx, SvtHipLane *l, bool make_stream) {
     if (l->ready) return SVT_HIP_OK;
-    if (make_stream) SVT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
-    if (hipMalloc(reinterpret_cast<void **>(&l->queue_head), 512) != hipSuccess || hipMemset(l->queue_head, 0, 512) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&l->params_dev), SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * SVT_HIP_ME_MAX_PICTURES) != hipSuccess)
+    // a set-up that failed part-way is retried by the lane's next holder: only the objects that do not exist yet are made
+    if (make_stream && !l->stream) SVT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    if (!l->queue_head) {
+        if (hipMalloc(reinterpret_cast<void **>(&l->queue_head), 512) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMalloc failed");
+        if (hipMemset(l->queue_head, 0, 512) != hipSuccess) { hipFree(l->queue_head); l->queue_head = nullptr; return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMemset failed"); }
+    }
+    if (!l->params_dev && hipMalloc(reinterpret_cast<void **>(&l->params_dev), SVT_HIP_ME_PARAM_BYTES) != hipSuccess)
         return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMalloc failed");
     for (int k = 0; k < SVT_HIP_PARAM_RING; k++) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&l->params_host[k]), SVT_HIP_ME_HEADER_BYTES + sizeof(MeKernelParams) * SVT_HIP_ME_MAX_PICTURES, hipHostMallocDefault) != hipSuccess)
+        if (!l->params_host[k] && hipHostMalloc(reinterpret_cast<void **>(&l->params_host[k]), SVT_HIP_ME_PARAM_BYTES, hipHostMallocDefault) != hipSuccess)
             return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipHostMalloc failed");
-        SVT_HIP_CHECK(ctx, hipEventCreateWithFlags(&l->params_copied[k], hipEventDisableTiming));
+        if (!l->params_copied[k]) SVT_HIP_CHECK(ctx, hipEventCreateWithFlags(&l->params_copied[k], hipEventDisableTiming));
     }
     l->ring_next = 0;
     l->ready     = true;

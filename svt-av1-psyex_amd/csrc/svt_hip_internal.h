@@ -28,6 +28,8 @@ struct SvtHipLane {
     int         ring_next;
     void       *scratch;     // result buffer of the synchronous entries, grown on demand (only touched by the lane's holder)
     size_t      scratch_bytes;
+    void       *dense;       // slots of the ME dense pre-pass (me_dense.inl), grown on demand
+    size_t      dense_bytes;
     bool        ready;       // device objects exist (lanes are set up on first use)
 };
 
@@ -42,6 +44,7 @@ struct SvtHipContext {
     uint32_t    lane_busy;             // bit i: lane i is borrowed
     int16_t    *iscan_dev;             // [19][3][1024] inverse scan orders (rd_kernel.hip), this device's copy
     bool        me_attr_set;           // hipFuncSetAttribute done for the ME kernel on this device
+    bool        me_dense;              // the dense pre-HME / level-0 pre-pass runs ahead of the per-block ME kernel (svt_hip_context_set_me_dense)
     uint32_t    me_waves_per_cu;       // 0: as many persistent ME waves per CU as fit; else an upper limit (svt_hip_context_set_me_waves_per_cu)
     hipStream_t io_stream;             // transfer stream of svt_hip_pa_picture_update_ahead (created on first use)
     hipEvent_t  io_fence;              // orders the transfer stream behind the context stream

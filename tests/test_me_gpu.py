@@ -216,3 +216,53 @@ def test_8k_picture_matches_oracle(hip_ctx):
     case = MeCase(7680, 4320, enc_mode=6, refs={(0, 0): 0, (1, 0): 2}, cur=1, n_frames=3, seed=3, temporal_layer_index=2)
     assert case.desc.input_resolution == 6
     assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
+
+
+# ---- the dense pre-pass (pre-HME strips + HME level-0 regions ahead of the per-block kernel: csrc/me_dense.inl) ----
+
+DENSE_CASES = [
+    dict(width=640, height=360, enc_mode=6, seed=21),                                         # bottom row 40 samples high: 5 source rows
+    dict(width=1280, height=720, enc_mode=6, refs={(0, 0): 0, (1, 0): 10}, cur=5, seed=22),    # distance 5: large strips, several segments
+    dict(width=1280, height=720, enc_mode=2, refs={(0, 0): 3, (0, 1): 1, (1, 0): 5, (1, 1): 7}, cur=4, seed=23, temporal_layer_index=2),
+    dict(width=360, height=296, enc_mode=4, seed=24, kind="noise"),                             # right column 40 samples wide: left to the per-block kernel
+    dict(width=1920, height=1080, enc_mode=8, seed=25),
+    dict(width=704, height=576, enc_mode=0, refs={(0, 0): 0, (1, 0): 9}, cur=8, seed=26, kind="fastpan"),
+]
+
+
+@pytest.mark.parametrize("kw", DENSE_CASES, ids=lambda k: f"{k['width']}x{k['height']}_m{k['enc_mode']}")
+def test_dense_prepass_is_used_and_changes_nothing(hip_ctx, kw):
+    """With the pre-pass on, the per-block kernel takes pre-HME / level-0 results from it (counter > 0) and every output -- the
+    search-level arrays included -- equals the run without it and the oracle."""
+    case = MeCase(**kw)
+    want = case.run_cpu("oracle")
+    try:
+        hip_ctx.set_me_dense(False)
+        hip_ctx.me_dense_counters()
+        off = case.run_hip(hip_ctx)
+        assert hip_ctx.me_dense_counters() == (0, 0)
+        hip_ctx.set_me_dense(True)
+        on = case.run_hip(hip_ctx)
+        taken, own = hip_ctx.me_dense_counters()
+    finally:
+        hip_ctx.set_me_dense(True)
+    assert not compare(want, off)
+    assert not compare(want, on)
+    assert taken > 0 and taken > 4 * own, (taken, own)
+
+
+def test_dense_prepass_skip_search_line_and_partial_octets(hip_ctx):
+    """prehme_skip_search_line (odd search rows only) and search widths that are not multiples of 8 after clipping."""
+    def edit(cfg):
+        cfg.prehme_skip_search_line = 1
+        cfg.prehme_sa_cfg[1].sa_min.width = 44
+        cfg.prehme_sa_cfg[1].sa_max.width = 100
+        cfg.prehme_sa_cfg[0].sa_min.height = 37
+        cfg.me_early_exit_th = 0
+    case = MeCase(416, 240, enc_mode=5, cfg_edit=edit, seed=31, kind="noise")
+    want = case.run_cpu("oracle")
+    hip_ctx.me_dense_counters()
+    got = case.run_hip(hip_ctx)
+    taken, own = hip_ctx.me_dense_counters()
+    assert not compare(want, got)
+    assert taken > 0
