@@ -6,9 +6,14 @@
  * path -- one call is microseconds of CPU work but three PCIe round trips here; production goes through the batched
  * entries (svt_hip_me_picture, svt_hip_rd_batch, svt_hip_block_stats_batch).
  *
- * The leaf kernels of the reference have no error channel and no context argument: bind a context once with
- * svt_hip_leaf_bind(); a call without one, or a device failure inside one, aborts the process (no CPU fallback).
- * Calls serialise on the bound context's stream (the symbols are reentrant through an internal lock).
+ * The leaf kernels of the reference have no error channel and no context argument: bind a context once with svt_hip_leaf_bind() (the
+ * installer does).  FAIL CLOSED: the reference's dispatch always leaves a working kernel in every pointer (Codec/aom_dsp_rtcd.c:38-48,73-99);
+ * an entry here that cannot run -- no bound context, a device error -- therefore calls, with the same arguments, the kernel the encoder had
+ * in the slot before svt_hip_install_rtcd / svt_hip_rtcd_store overwrote it (the encoder's own SIMD or `_c` body), and keeps the failure
+ * for svt_hip_leaf_status() / svt_hip_last_error() of the calling thread.  Nothing aborts.  An entry that was called directly (no installer,
+ * hence no previous kernel) records the failure and returns zero / leaves its outputs alone.
+ * The binding is PROCESS-GLOBAL and the entries run one at a time under one lock on the bound context's stream: this layer is the
+ * validation / drop-in path and is single-stream by construction; concurrency lives in the batched entries.
  */
 #ifndef SVT_HIP_LEAF_H
 #define SVT_HIP_LEAF_H
@@ -36,6 +41,14 @@ typedef struct SvtHipRtcdSlot {
 } SvtHipRtcdSlot;
 int         svt_hip_install_rtcd(SvtHipContext *ctx, const SvtHipRtcdSlot *slots, uint32_t n_slots, uint32_t *n_skipped);
 const void *svt_hip_rtcd_lookup(const char *name);
+/* The installer's first half alone: stores the entries and records the slots' previous kernels, binds no context -- every call goes to
+ * the previous kernels until svt_hip_leaf_bind().  svt_hip_uninstall_rtcd puts the previous kernels back into the slots. */
+int         svt_hip_rtcd_store(const SvtHipRtcdSlot *slots, uint32_t n_slots, uint32_t *n_skipped);
+int         svt_hip_uninstall_rtcd(const SvtHipRtcdSlot *slots, uint32_t n_slots);
+/* Since the last call: calls served by previous kernels, calls that failed with nowhere to go, the last failure's text (any pointer may
+ * be null); returns the sum of the two counts.  svt_hip_leaf_inject_failure(1) makes every entry fail as if the device had (testing). */
+int         svt_hip_leaf_status(unsigned long long *fallbacks, unsigned long long *unhandled, char *message, size_t message_bytes);
+void        svt_hip_leaf_inject_failure(int on);
 
 /* svt_sad_loop_kernel (aom_dsp_rtcd.h:779; C_DEFAULT/compute_sad_c.c:58-101) */
 void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,

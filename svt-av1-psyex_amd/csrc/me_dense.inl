@@ -123,13 +123,24 @@ svt_hip_me_dense_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPa
     for (int i = 0; i < 16; i++) { acc0[i] = 0; acc1[i] = 0; }
 
     const int n_oct_iter = (int)(((uint32_t)e.noct + (uint32_t)nos - 1u) / (uint32_t)nos); // uniform
+    typedef uint32_t V2U __attribute__((ext_vector_type(2), aligned(1)));
+    typedef const __attribute__((address_space(1))) V2U GV2U;
+    // byte offset of octet iteration oi's window in a reference row (lanes past their clipped width read their first octet again: unused)
+    auto octet_off = [&](int oi) { const int o = oslot + oi * nos; return (uint32_t)(x_first + 8 * ((active && o < noct_l) ? o : 0)); };
+    // the first row of an octet's walk is fetched while the previous octet is still being evaluated
+    V4U  nfa;
+    V2U  nfb;
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(row0 + (long long)Rp_begin * stride) + octet_off(0);
+        nfa = *reinterpret_cast<GV4U *>(a);
+        nfb = *reinterpret_cast<GV2U *>(a + 16);
+    }
     for (int oi = 0; oi < n_oct_iter; oi++) {
         const int  o     = oslot + oi * nos;
         const bool live  = active && o < noct_l;
-        const int  o_adr = live ? o : 0;
         const int  nvalid = live ? imin(8, g.sa_w - 8 * o) : 0; // positions of the octet inside the search width
         const bool all_full = __all(nvalid == 8);
-        const uint32_t loff = (uint32_t)(x_first + 8 * o_adr);
+        const uint32_t loff = octet_off(oi);
         uint32_t best = 0xFFFFFFFFu; // sad << 16 | position in the octet
         int      bestd = 0;
         V4U  bufa[2];
@@ -137,11 +148,15 @@ svt_hip_me_dense_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPa
         auto fetch = [&](int which, int Rp) {
             const uintptr_t a = reinterpret_cast<uintptr_t>(row0 + (long long)Rp * stride) + loff;
             bufa[which] = *reinterpret_cast<GV4U *>(a);
-            typedef uint32_t V2U __attribute__((ext_vector_type(2), aligned(1)));
-            const V2U q = *reinterpret_cast<const __attribute__((address_space(1))) V2U *>(a + 16);
+            const V2U q = *reinterpret_cast<GV2U *>(a + 16);
             bufb[which] = make_uint2(q.x, q.y);
         };
-        fetch(Rp_begin & 1, Rp_begin);
+        bufa[0] = nfa; bufb[0] = make_uint2(nfb.x, nfb.y); // Rp_begin = 2 kfirst is even: step Rp_begin reads slot 0
+        if (oi + 1 < n_oct_iter) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(row0 + (long long)Rp_begin * stride) + octet_off(oi + 1);
+            nfa = *reinterpret_cast<GV4U *>(a);
+            nfb = *reinterpret_cast<GV2U *>(a + 16);
+        }
         for (int it = 0; it * 16 <= Rp_end; it++) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -229,7 +244,9 @@ uint32_t dense_plan(const MeKernelParams *params, const uint32_t *n_jobs, uint32
                     e.seg_len = (uint16_t)((sa_h + e.n_seg - 1) / e.n_seg);
                     const uint32_t groups = (uint32_t)e.noct * e.seg_len * 8u; // of one block
                     uint32_t nos = (groups + kDenseTargetGroups - 1) / kDenseTargetGroups;
-                    e.nos = (uint16_t)(nos < 1 ? 1 : (nos > e.noct ? e.noct : nos));
+                    nos = nos < 1 ? 1 : (nos > e.noct ? e.noct : nos);
+                    while (e.noct % nos) nos++; // a divisor of the octet count: every lane of a block walks the same number of octets
+                    e.nos = (uint16_t)nos;
                     e.n_chunk = (uint16_t)((p.w64 * e.nos + 63u) / 64u);
                     e.n_rows = (uint16_t)(n_jobs[pi] / p.w64);
                     cost[n].cost = ((uint32_t)e.noct + e.nos - 1u) / e.nos * e.seg_len;

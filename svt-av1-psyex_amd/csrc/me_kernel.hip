@@ -1138,8 +1138,8 @@ __device__ __forceinline__ void key_to_result(u64 key, int full, uint32_t &sad, 
 }
 
 // zero-MV style SAD request: svt_nxm_sad_kernel on every other row (get_zz_sad, motion_estimation.c:1667-1689)
-__device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy) {
-    push_req(st, plane_at(rp, (int)st.org_x + dx, (int)st.org_y + dy), rp.stride, 1, 1, (int)st.b64_w, (int)st.b64_h >> 1, 2, 2, 0);
+__device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy, int slot = -1) {
+    push_req(st, plane_at(rp, (int)st.org_x + dx, (int)st.org_y + dy), rp.stride, 1, 1, (int)st.b64_w, (int)st.b64_h >> 1, 2, 2, 0, slot);
 }
 
 } // namespace
@@ -1294,108 +1294,102 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         auto zz_pre = [&]() {
             if (tid == 0) st.nreq = 0; // the SADs came with the block set-up
         };
-        auto zz_post = [&]() {
-            if (tid == 0) {
-                uint32_t best = 0xFFFFFFFFu;
-                int      k    = 0;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
-                        if (searched(p, li)) {
-                            uint32_t z = (uint32_t)(st.req_key[k++] >> 32) << 1;
-                            z = (z * 64 * 64) / (st.b64_w * st.b64_h);
-                            st.zz_sad[li][ri] = z;
-                            best = z < best ? z : best;
-                        }
-                if (d.temporal_layer_index > 0 && best < c.zz_sad_th)
-                    for (int li = 0; li < nl; li++)
-                        for (int ri = 1; ri < d.num_of_ref_pic_to_search[li]; ri++)
-                            if ((uint32_t)((st.zz_sad[li][ri] - best) * 100) > (uint32_t)(c.zz_sad_pct * best)) st.do_ref[li][ri] = 0;
-                if (c.me_safe_limit_zz_th) {
-                    const bool limit = d.hierarchical_levels > 0 && nl == 2 && d.temporal_layer_index >= d.hierarchical_levels &&
-                        d.similar_brightness_refs && st.zz_sad[0][0] < c.me_safe_limit_zz_th && st.zz_sad[1][0] < c.me_safe_limit_zz_th;
-                    if (limit)
-                        for (int li = 0; li < nl; li++)
-                            for (int ri = 1; ri < d.num_of_ref_pic_to_search[li]; ri++) st.do_ref[li][ri] = 0;
-                }
+        auto zz_post = [&]() { // lane <-> (list, reference); the reference's serial loops become wave reductions
+            const int  li = (tid >> 2) & 1, ri = tid & 3;
+            const bool valid = tid < 8 && li < nl && ri < d.num_of_ref_pic_to_search[li];
+            const bool srch  = valid && searched(p, li);
+            const u64  smask = __ballot(srch);
+            uint32_t   z = 0xFFFFFFFFu;
+            if (srch) {
+                const int k = __popcll(smask & ((1ull << tid) - 1ull)); // the searched pairs in the reference's loop order
+                z = (uint32_t)(st.req_key[k] >> 32) << 1;
+                z = (z * 64 * 64) / (st.b64_w * st.b64_h);
+                st.zz_sad[li][ri] = z;
+            }
+            const uint32_t best = wave_min_u32(z);
+            if (d.temporal_layer_index > 0 && best < c.zz_sad_th && valid && ri >= 1)
+                if ((uint32_t)((z - best) * 100) > (uint32_t)(c.zz_sad_pct * best)) st.do_ref[li][ri] = 0; // (every list is searched when the layer is above 0)
+            if (c.me_safe_limit_zz_th) {
+                wave_sync();
+                const bool limit = d.hierarchical_levels > 0 && nl == 2 && d.temporal_layer_index >= d.hierarchical_levels &&
+                    d.similar_brightness_refs && st.zz_sad[0][0] < c.me_safe_limit_zz_th && st.zz_sad[1][0] < c.me_safe_limit_zz_th;
+                if (limit && valid && ri >= 1) st.do_ref[li][ri] = 0;
             }
         };
         // ---- prehme_b64 (motion_estimation.c:1693-1796) ---------------------------------------------------
         // with l1_early_exit, list 1 looks at list 0's results: one batch per list then
-        auto prehme_pre = [&](int bi) {
-            const int l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
-            if (tid == 0) {
-                st.nreq = 0;
-                for (int li = l_lo; li < l_hi; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        st.ph_req[li][ri][0] = st.ph_req[li][ri][1] = 0;
-                        if (!searched(p, li)) continue;
-                        for (int sri = 0; sri < 2; sri++) {
-                            PreHme &ph = st.prehme[li][ri][sri];
-                            // check_prehme_early_exit (:1693-1720)
-                            if (c.me_early_exit_th && st.zz_sad[li][ri] < c.me_early_exit_th) { ph.col = ph.row = 0; ph.sad = 0; ph.valid = 1; continue; }
-                            if (c.prehme_l1_early_exit) {
-                                const PreHme &q = st.prehme[0][ri][sri];
-                                if (li == 1 && q.valid && (q.sad < 32 * 32 || (iabs(q.col) < 16 && iabs(q.row) < 16))) {
-                                    ph.col = (int16_t)-q.col; ph.row = (int16_t)-q.row; ph.sad = q.sad; ph.valid = 1; continue;
-                                }
-                            }
-                            if (!st.do_ref[li][ri]) { ph.col = ph.row = 0; ph.sad = 0xFFFFFFFFu; continue; }
-                            // prehme_core (:1568-1666)
-                            CPlane &rp = p.ref[li][ri].lvl[0];
-                            const int ox16 = (int16_t)st.org_x >> 2, oy16 = (int16_t)st.org_y >> 2;
-                            const SearchGeo sg = prehme_geometry(p, li, ri, sri, st.org_x, st.org_y);
-                            const int ox = sg.ox, oy = sg.oy;
-                            push_hme_req(st, p, 0, rp, ox16, oy16, (int)st.b64_w >> 2, (int)st.b64_h >> 2, ox, oy, sg.sa_w, sg.sa_h, c.prehme_skip_search_line);
-                            st.ph_req[li][ri][sri] = (uint8_t)st.nreq;
-                            dense_take(st, dense_lds, (((li ? r0n : 0) + ri) * kDenseKinds + sri), st.nreq - 1, sg, n_hit, n_miss);
-                            ph.col = (int16_t)ox; ph.row = (int16_t)oy; // search origin until the result is folded in
-                            st.performed_phme[li][ri][sri] = 1;
+        auto prehme_pre = [&](int bi) { // lane <-> (list, reference, strip) in the reference's loop order; request numbers = prefix count of the pushing lanes
+            const int  l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
+            const int  li = (tid >> 3) & 1, ri = (tid >> 1) & 3, sri = tid & 1;
+            const bool mine = tid < 16 && li >= l_lo && li < l_hi && ri < d.num_of_ref_pic_to_search[li];
+            bool       push = false;
+            if (mine) {
+                st.ph_req[li][ri][sri] = 0;
+                if (searched(p, li)) {
+                    PreHme &ph = st.prehme[li][ri][sri];
+                    bool    handled = false;
+                    // check_prehme_early_exit (:1693-1720)
+                    if (c.me_early_exit_th && st.zz_sad[li][ri] < c.me_early_exit_th) { ph.col = ph.row = 0; ph.sad = 0; ph.valid = 1; handled = true; }
+                    if (!handled && c.prehme_l1_early_exit) {
+                        const PreHme &q = st.prehme[0][ri][sri];
+                        if (li == 1 && q.valid && (q.sad < 32 * 32 || (iabs(q.col) < 16 && iabs(q.row) < 16))) {
+                            ph.col = (int16_t)-q.col; ph.row = (int16_t)-q.row; ph.sad = q.sad; ph.valid = 1; handled = true;
                         }
                     }
+                    if (!handled && !st.do_ref[li][ri]) { ph.col = ph.row = 0; ph.sad = 0xFFFFFFFFu; handled = true; }
+                    push = !handled;
+                }
             }
+            const u64 mask = __ballot(push);
+            const int slot = __popcll(mask & ((1ull << tid) - 1ull));
+            if (push) {
+                // prehme_core (:1568-1666)
+                PreHme &ph = st.prehme[li][ri][sri];
+                CPlane &rp = p.ref[li][ri].lvl[0];
+                const int ox16 = (int16_t)st.org_x >> 2, oy16 = (int16_t)st.org_y >> 2;
+                const SearchGeo sg = prehme_geometry(p, li, ri, sri, st.org_x, st.org_y);
+                push_hme_req(st, p, 0, rp, ox16, oy16, (int)st.b64_w >> 2, (int)st.b64_h >> 2, sg.ox, sg.oy, sg.sa_w, sg.sa_h, c.prehme_skip_search_line, slot);
+                st.ph_req[li][ri][sri] = (uint8_t)(slot + 1);
+                dense_take(st, dense_lds, (((li ? r0n : 0) + ri) * kDenseKinds + sri), slot, sg, n_hit, n_miss);
+                ph.col = (int16_t)sg.ox; ph.row = (int16_t)sg.oy; // search origin until the result is folded in
+                st.performed_phme[li][ri][sri] = 1;
+            }
+            if (tid == 0) st.nreq = __popcll(mask);
         };
         auto prehme_post = [&](int bi) {
-            const int l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
-            if (tid == 0) {
-                for (int li = l_lo; li < l_hi; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++)
-                        for (int sri = 0; sri < 2; sri++) {
-                            const int k = st.ph_req[li][ri][sri];
-                            if (!k) continue;
-                            PreHme &ph = st.prehme[li][ri][sri];
-                            uint32_t sad; int x, y;
-                            key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
-                            ph.sad = sad;
-                            ph.col = (int16_t)((int16_t)(x + ph.col) * 4);
-                            ph.row = (int16_t)((int16_t)(y + ph.row) * 4);
-                            ph.valid = 1;
-                        }
+            const int  l_lo = c.prehme_l1_early_exit ? bi : 0, l_hi = c.prehme_l1_early_exit ? bi + 1 : nl;
+            const int  li = (tid >> 3) & 1, ri = (tid >> 1) & 3, sri = tid & 1;
+            const bool mine = tid < 16 && li >= l_lo && li < l_hi && ri < d.num_of_ref_pic_to_search[li];
+            const int  k = mine ? st.ph_req[li][ri][sri] : 0;
+            if (k) {
+                PreHme &ph = st.prehme[li][ri][sri];
+                uint32_t sad; int x, y;
+                key_to_result(st.req_key[k - 1], full_hme, sad, x, y);
+                ph.sad = sad;
+                ph.col = (int16_t)((int16_t)(x + ph.col) * 4);
+                ph.row = (int16_t)((int16_t)(y + ph.row) * 4);
+                ph.valid = 1;
             }
         };
-        auto prehme_final = [&]() {
-            if (tid == 0) {
-                uint32_t best_sad = 0xFFFFFFFFu;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (searched(p, li)) {
-                            const uint32_t m = st.prehme[li][ri][0].sad < st.prehme[li][ri][1].sad ? st.prehme[li][ri][0].sad : st.prehme[li][ri][1].sad;
-                            best_sad = m < best_sad ? m : best_sad;
-                        } else {
-                            for (int sri = 0; sri < 2; sri++) {
-                                st.prehme[1][ri][sri].col = (int16_t)-st.prehme[0][ri][sri].col;
-                                st.prehme[1][ri][sri].row = (int16_t)-st.prehme[0][ri][sri].row;
-                                st.prehme[1][ri][sri].sad = st.prehme[0][ri][sri].sad;
-                            }
-                        }
+        auto prehme_final = [&]() { // lane <-> (list, reference)
+            wave_sync(); // the strips' results
+            const int  li = (tid >> 2) & 1, ri = tid & 3;
+            const bool valid = tid < 8 && li < nl && ri < d.num_of_ref_pic_to_search[li];
+            uint32_t   m = 0xFFFFFFFFu;
+            if (valid) {
+                if (searched(p, li)) {
+                    m = st.prehme[li][ri][0].sad < st.prehme[li][ri][1].sad ? st.prehme[li][ri][0].sad : st.prehme[li][ri][1].sad;
+                } else { // list 1 of a base-layer picture mirrors list 0 (the reference writes list 1's entries here)
+                    for (int sri = 0; sri < 2; sri++) {
+                        st.prehme[1][ri][sri].col = (int16_t)-st.prehme[0][ri][sri].col;
+                        st.prehme[1][ri][sri].row = (int16_t)-st.prehme[0][ri][sri].row;
+                        st.prehme[1][ri][sri].sad = st.prehme[0][ri][sri].sad;
                     }
-                if (d.temporal_layer_index > 0 && best_sad < c.phme_sad_th)
-                    for (int li = 0; li < nl; li++)
-                        for (int ri = 1; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                            if (!st.do_ref[li][ri]) continue;
-                            const uint32_t m = st.prehme[li][ri][0].sad < st.prehme[li][ri][1].sad ? st.prehme[li][ri][0].sad : st.prehme[li][ri][1].sad;
-                            if ((uint32_t)((m - best_sad) * 100) > (uint32_t)(c.phme_sad_pct * best_sad)) st.do_ref[li][ri] = 0;
-                        }
+                }
             }
+            const uint32_t best_sad = wave_min_u32(m);
+            if (d.temporal_layer_index > 0 && best_sad < c.phme_sad_th && valid && ri >= 1 && st.do_ref[li][ri]) // (every list is searched when the layer is above 0)
+                if ((uint32_t)((m - best_sad) * 100) > (uint32_t)(c.phme_sad_pct * best_sad)) st.do_ref[li][ri] = 0;
         };
         // ---- hme_level0_b64 (motion_estimation.c:1906-2036) ------------------------------------------
         // get_hme_l0_search_area reads list0/ref0's level-0 result only when both thresholds are set
@@ -1530,38 +1524,40 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             }
         };
         // ---- set_final_seach_centre_sb (:2182-2380), hme_prune_ref_and_adjust_sr (:2477-2518) -------------
-        auto centre = [&]() {
-            if (tid == 0) {
-                {
-                    int16_t cx = 0, cy = 0, sx = 0, sy = 0;
-                    u64     hme_sad = 0; // survives across refs, like the reference's local
-                    for (int li = 0; li < nl; li++)
-                        for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                            if (searched(p, li)) {
-                                if (c.enable_hme_flag) {
-                                    int lvl = -1;
-                                    if (c.enable_hme_level0_flag && !c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 0;
-                                    if (c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 1;
-                                    if (c.enable_hme_level2_flag) lvl = 2;
-                                    if (lvl >= 0) {
-                                        cx = st.hx[lvl][li][ri][0][0]; cy = st.hy[lvl][li][ri][0][0]; hme_sad = st.hs[lvl][li][ri][0][0];
-                                        int w = 1;
-                                        for (int h = 0; h < c.num_hme_sa_h; h++) {
-                                            for (; w < c.num_hme_sa_w; w++)
-                                                if (st.hs[lvl][li][ri][w][h] < hme_sad) {
-                                                    cx = st.hx[lvl][li][ri][w][h]; cy = st.hy[lvl][li][ri][w][h]; hme_sad = st.hs[lvl][li][ri][w][h];
-                                                }
-                                            w = 0;
-                                        }
-                                    }
-                                    sx = cx; sy = cy;
+        auto centre = [&]() { // lane <-> (list, reference)
+            {
+                const int  li = (tid >> 2) & 1, ri = tid & 3;
+                const bool valid = tid < 8 && li < nl && ri < d.num_of_ref_pic_to_search[li];
+                const bool srch  = valid && searched(p, li);
+                int16_t sx = 0, sy = 0;
+                u64     hme_sad = 0;
+                if (srch && c.enable_hme_flag) {
+                    int16_t cx = 0, cy = 0;
+                    int lvl = -1;
+                    if (c.enable_hme_level0_flag && !c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 0;
+                    if (c.enable_hme_level1_flag && !c.enable_hme_level2_flag) lvl = 1;
+                    if (c.enable_hme_level2_flag) lvl = 2;
+                    if (lvl >= 0) {
+                        cx = st.hx[lvl][li][ri][0][0]; cy = st.hy[lvl][li][ri][0][0]; hme_sad = st.hs[lvl][li][ri][0][0];
+                        int w = 1;
+                        for (int h = 0; h < c.num_hme_sa_h; h++) {
+                            for (; w < c.num_hme_sa_w; w++)
+                                if (st.hs[lvl][li][ri][w][h] < hme_sad) {
+                                    cx = st.hx[lvl][li][ri][w][h]; cy = st.hy[lvl][li][ri][w][h]; hme_sad = st.hs[lvl][li][ri][w][h];
                                 }
-                            } else { sx = sy = 0; }
-                            st.hme_sc_x[li][ri] = sx; st.hme_sc_y[li][ri] = sy; st.hme_sad64[li][ri] = hme_sad;
+                            w = 0;
                         }
+                    }
+                    sx = cx; sy = cy;
                 }
+                // the reference's local hme_sad survives across the loop's iterations: a pair that is not searched (list 1 of a base-layer
+                // picture) is left with the value of the last searched one in loop order -- list 0's last reference
+                const int last0 = d.num_of_ref_pic_to_search[0] - 1;
+                const u64 carry = ((u64)(uint32_t)__shfl((int)(uint32_t)(hme_sad >> 32), last0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)hme_sad, last0, 64);
+                if (valid && !srch) hme_sad = carry;
+                if (valid) { st.hme_sc_x[li][ri] = sx; st.hme_sc_y[li][ri] = sy; st.hme_sad64[li][ri] = hme_sad; }
                 // ME_MCTF leaves after HME when list0/ref0 already matches (motion_estimation.c:3109-3113)
-                st.tf_exit = mctf && st.hme_sad64[0][0] < (u64)d.tf_me_exit_th;
+                if (tid == 0) st.tf_exit = mctf && hme_sad < (u64)d.tf_me_exit_th;
             }
             if (c.enable_hme_flag && !mctf) { // hme_prune_ref_and_adjust_sr (skipped for ME_MCTF, :3103,3115): lane <-> (list, reference)
                 wave_sync();
@@ -1588,81 +1584,83 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         // zz early exit is off); then list0/ref0 is finished first.  Per group: (a) check_00_center SADs,
         // (b) search-area sizing and the 1-point probe for the 8x8-variance test, (c) final window, full search.
         const bool me_dep = (!c.me_early_exit_th) && c.enable_me_sr_adjustment == 2;
-        auto c00_pre = [&](int gi) {
+        auto c00_pre = [&](int gi) { // lane <-> (list, reference)
             const bool dep = me_dep;
-            if (tid == 0) {
-                st.nreq = 0;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
-                        st.c00_req[li][ri] = 0;
-                        st.me_cx[li][ri] = st.hme_sc_x[li][ri]; st.me_cy[li][ri] = st.hme_sc_y[li][ri];
-                        if (c.me_early_exit_th || !st.do_ref[li][ri]) continue;
-                        int16_t cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
-                        if ((cx != 0 || cy != 0) && d.is_ref) { // check_00_center (:1139-1206)
-                            CPlane &rp = p.ref[li][ri].lvl[2];
-                            const int ox = (int16_t)st.org_x, oy = (int16_t)st.org_y;
-                            if (ox + cx < -63) cx = (int16_t)(-63 - ox);
-                            if (ox + cx > rp.width - 1) cx = (int16_t)(cx - ((ox + cx) - (rp.width - 1)));
-                            if (oy + cy < -63) cy = (int16_t)(-63 - oy);
-                            if (oy + cy > rp.height - 1) cy = (int16_t)(cy - ((oy + cy) - (rp.height - 1)));
-                            st.me_cx[li][ri] = cx; st.me_cy[li][ri] = cy;
-                            push_zz_req(st, rp, 0, 0);
-                            push_zz_req(st, rp, cx, cy);
-                            st.c00_req[li][ri] = (uint8_t)st.nreq; // index of the second request + 1
-                        }
-                    }
+            const int  li = (tid >> 2) & 1, ri = tid & 3;
+            const bool mine = tid < 8 && li < nl && ri < d.num_of_ref_pic_to_search[li] && !(dep && ((li == 0 && ri == 0) != (gi == 0)));
+            bool    push = false;
+            int16_t cx = 0, cy = 0;
+            if (mine) {
+                st.c00_req[li][ri] = 0;
+                cx = st.hme_sc_x[li][ri]; cy = st.hme_sc_y[li][ri];
+                st.me_cx[li][ri] = cx; st.me_cy[li][ri] = cy;
+                push = !(c.me_early_exit_th || !st.do_ref[li][ri]) && (cx != 0 || cy != 0) && d.is_ref;
             }
+            const u64 mask = __ballot(push);
+            const int slot = 2 * __popcll(mask & ((1ull << tid) - 1ull));
+            if (push) { // check_00_center (:1139-1206)
+                CPlane &rp = p.ref[li][ri].lvl[2];
+                const int ox = (int16_t)st.org_x, oy = (int16_t)st.org_y;
+                if (ox + cx < -63) cx = (int16_t)(-63 - ox);
+                if (ox + cx > rp.width - 1) cx = (int16_t)(cx - ((ox + cx) - (rp.width - 1)));
+                if (oy + cy < -63) cy = (int16_t)(-63 - oy);
+                if (oy + cy > rp.height - 1) cy = (int16_t)(cy - ((oy + cy) - (rp.height - 1)));
+                st.me_cx[li][ri] = cx; st.me_cy[li][ri] = cy;
+                push_zz_req(st, rp, 0, 0, slot);
+                push_zz_req(st, rp, cx, cy, slot + 1);
+                st.c00_req[li][ri] = (uint8_t)(slot + 2); // index of the second request + 1
+            }
+            if (tid == 0) st.nreq = 2 * __popcll(mask);
         };
-        auto probe_pre = [&](int gi) {
+        auto probe_pre = [&](int gi) { // lane <-> (list, reference); list entries in the reference's loop order (prefix count of the lanes that search)
             const bool dep = me_dep;
-            if (tid == 0) {
-                st.nme = 0; st.nprobe = 0;
-                for (int li = 0; li < nl; li++)
-                    for (int ri = 0; ri < d.num_of_ref_pic_to_search[li]; ri++) {
-                        if (dep && ((li == 0 && ri == 0) != (gi == 0))) continue;
-                        if (!st.do_ref[li][ri]) continue;
-                        CPlane &rp = p.ref[li][ri].lvl[2];
-                        int16_t  cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
-                        const uint32_t dist = mctf ? (uint16_t)ref_distance(p, li, ri) : (uint16_t)scaled_distance(ref_distance(p, li, ri)); // :1299-1302
-                        int16_t sa_w = (int16_t)imin((int)(c.me_sa.sa_min.width * dist), c.me_sa.sa_max.width);
-                        int16_t sa_h = (int16_t)imin((int)(c.me_sa.sa_min.height * dist), c.me_sa.sa_max.height);
-                        if (c.mv_sa_adj_enabled && (!c.mv_sa_adj_nearest_ref_only || ri == 0)) {
-                            if (iabs(st.hme_sc_x[li][ri]) > c.mv_sa_adj_mv_size_th) sa_w = (int16_t)(sa_w * c.mv_sa_adj_sa_multiplier);
-                            if (iabs(st.hme_sc_y[li][ri]) > c.mv_sa_adj_mv_size_th) sa_h = (int16_t)(sa_h * c.mv_sa_adj_sa_multiplier);
-                        }
-                        { const uint32_t q = (uint32_t)(int)sa_w / st.sr_divisor[li][ri]; sa_w = (int16_t)(((q > 1u ? q : 1u) + 7) & ~7u); }
-                        { const uint32_t q = (uint32_t)(int)sa_h / st.sr_divisor[li][ri]; sa_h = (int16_t)(q > 3u ? q : 3u); }
-                        const int16_t h0 = sa_h, w0 = sa_w;
-                        u64 best_hme_sad = ~0ull;
-                        if (c.me_early_exit_th) {
-                            if (st.zz_sad[li][ri] < c.me_early_exit_th / 6) sa_w = sa_h = 1;
-                        } else {
-                            int accurate = 1;
-                            const int k2 = st.c00_req[li][ri];
-                            if (k2) {
-                                const uint32_t zero = (uint32_t)(st.req_key[k2 - 2] >> 32) << 1;
-                                const uint32_t hme  = (uint32_t)(st.req_key[k2 - 1] >> 32) << 1;
-                                if (zero <= hme) cx = cy = 0; // MIN(zero_cost, hme_cost) == zero_cost
-                                best_hme_sad = hme;
-                                if (cx == 0 && cy == 0) accurate = 0;
-                            }
-                            if (c.enable_me_sr_adjustment == 2) {
-                                if ((accurate && best_hme_sad < 24 * 24) || (d.is_ref && st.hme_sad64[li][ri] < 24 * 24)) sa_h = (int16_t)(sa_h / 2);
-                                if ((li || ri) && BEST_SAD(0, 0)[0] < 5000 && sa_h == h0 && sa_w == w0) { sa_h = (int16_t)(sa_h >> 1); sa_w = (int16_t)(sa_w >> 1); }
-                            }
-                        }
-                        MeReq &m = st.me[st.nme++];
-                        m.pix0 = plane_at(rp, (int)st.org_x, (int)st.org_y); m.stride = rp.stride;
-                        m.min_x = (int16_t)(-rp.org_x - (int)st.org_x); m.max_x = (int16_t)(rp.width + rp.org_x - 1 - (int)st.org_x);
-                        m.min_y = (int16_t)(-rp.org_y - (int)st.org_y); m.max_y = (int16_t)(rp.height + rp.org_y - 1 - (int)st.org_y);
-                        m.li = (uint8_t)li; m.ri = (uint8_t)ri; m.pad = 0;
-                        m.sa_w = sa_w; m.sa_h = sa_h; // provisional size, finalised after the probe
-                        m.ox = cx; m.oy = cy;         // the search centre until then
-                        m.probe = (c.me_8x8_var_enabled && sa_w * sa_h > 24) ? 1 : 0;
-                        if (m.probe) { MeReq &pr = st.me_probe[st.nprobe++]; pr = m; pr.sa_w = pr.sa_h = 1; }
+            const int  li = (tid >> 2) & 1, ri = tid & 3;
+            const bool mine = tid < 8 && li < nl && ri < d.num_of_ref_pic_to_search[li] && !(dep && ((li == 0 && ri == 0) != (gi == 0))) && st.do_ref[li][ri];
+            MeReq m = {};
+            if (mine) {
+                CPlane &rp = p.ref[li][ri].lvl[2];
+                int16_t  cx = st.me_cx[li][ri], cy = st.me_cy[li][ri];
+                const uint32_t dist = mctf ? (uint16_t)ref_distance(p, li, ri) : (uint16_t)scaled_distance(ref_distance(p, li, ri)); // :1299-1302
+                int16_t sa_w = (int16_t)imin((int)(c.me_sa.sa_min.width * dist), c.me_sa.sa_max.width);
+                int16_t sa_h = (int16_t)imin((int)(c.me_sa.sa_min.height * dist), c.me_sa.sa_max.height);
+                if (c.mv_sa_adj_enabled && (!c.mv_sa_adj_nearest_ref_only || ri == 0)) {
+                    if (iabs(st.hme_sc_x[li][ri]) > c.mv_sa_adj_mv_size_th) sa_w = (int16_t)(sa_w * c.mv_sa_adj_sa_multiplier);
+                    if (iabs(st.hme_sc_y[li][ri]) > c.mv_sa_adj_mv_size_th) sa_h = (int16_t)(sa_h * c.mv_sa_adj_sa_multiplier);
+                }
+                { const uint32_t q = (uint32_t)(int)sa_w / st.sr_divisor[li][ri]; sa_w = (int16_t)(((q > 1u ? q : 1u) + 7) & ~7u); }
+                { const uint32_t q = (uint32_t)(int)sa_h / st.sr_divisor[li][ri]; sa_h = (int16_t)(q > 3u ? q : 3u); }
+                const int16_t h0 = sa_h, w0 = sa_w;
+                u64 best_hme_sad = ~0ull;
+                if (c.me_early_exit_th) {
+                    if (st.zz_sad[li][ri] < c.me_early_exit_th / 6) sa_w = sa_h = 1;
+                } else {
+                    int accurate = 1;
+                    const int k2 = st.c00_req[li][ri];
+                    if (k2) {
+                        const uint32_t zero = (uint32_t)(st.req_key[k2 - 2] >> 32) << 1;
+                        const uint32_t hme  = (uint32_t)(st.req_key[k2 - 1] >> 32) << 1;
+                        if (zero <= hme) cx = cy = 0; // MIN(zero_cost, hme_cost) == zero_cost
+                        best_hme_sad = hme;
+                        if (cx == 0 && cy == 0) accurate = 0;
                     }
+                    if (c.enable_me_sr_adjustment == 2) {
+                        if ((accurate && best_hme_sad < 24 * 24) || (d.is_ref && st.hme_sad64[li][ri] < 24 * 24)) sa_h = (int16_t)(sa_h / 2);
+                        if ((li || ri) && BEST_SAD(0, 0)[0] < 5000 && sa_h == h0 && sa_w == w0) { sa_h = (int16_t)(sa_h >> 1); sa_w = (int16_t)(sa_w >> 1); }
+                    }
+                }
+                m.pix0 = plane_at(rp, (int)st.org_x, (int)st.org_y); m.stride = rp.stride;
+                m.min_x = (int16_t)(-rp.org_x - (int)st.org_x); m.max_x = (int16_t)(rp.width + rp.org_x - 1 - (int)st.org_x);
+                m.min_y = (int16_t)(-rp.org_y - (int)st.org_y); m.max_y = (int16_t)(rp.height + rp.org_y - 1 - (int)st.org_y);
+                m.li = (uint8_t)li; m.ri = (uint8_t)ri; m.pad = 0;
+                m.sa_w = sa_w; m.sa_h = sa_h; // provisional size, finalised after the probe
+                m.ox = cx; m.oy = cy;         // the search centre until then
+                m.probe = (c.me_8x8_var_enabled && sa_w * sa_h > 24) ? 1 : 0;
             }
+            const bool probe = mine && m.probe;
+            const u64  mask = __ballot(mine), pmask = __ballot(probe), below = (1ull << tid) - 1ull;
+            if (mine) st.me[__popcll(mask & below)] = m;
+            if (probe) { MeReq pr = m; pr.sa_w = pr.sa_h = 1; st.me_probe[__popcll(pmask & below)] = pr; }
+            if (tid == 0) { st.nme = __popcll(mask); st.nprobe = __popcll(pmask); }
         };
         auto main_pre = [&]() {
             if (tid < 64) { // wave 0: the 8x8-SAD variance is a wave reduction, lane 0 keeps the result

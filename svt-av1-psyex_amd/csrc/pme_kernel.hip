@@ -10,6 +10,7 @@
 #include <mutex>
 #include <string.h>
 #include "svt_hip_internal.h"
+#include "leaf_guard.h"
 #include "../../include/svt_hip_pme.h"
 
 namespace {
@@ -96,7 +97,6 @@ __global__ void __launch_bounds__(64) pme_sad_kernel(const PmeParams p) {
     }
 }
 
-std::mutex g_pme_leaf_mutex;
 } // namespace
 
 extern "C" int svt_hip_pme_sad_batch(SvtHipContext *ctx, const SvtHipPmeBatchDesc *d) {
@@ -115,56 +115,55 @@ extern "C" int svt_hip_pme_sad_batch(SvtHipContext *ctx, const SvtHipPmeBatchDes
 }
 
 // ---- pointer-level entry (the reference's prototype, host pointers, synchronous) ----
-extern "C" int svt_hip_leaf_context(SvtHipContext **out); // stats_kernel.hip: the context bound with svt_hip_leaf_bind (aborts without one)
-
+// Like every pointer-level entry it fails closed (leaf_guard.h): without a bound context or on a device error the call goes to the kernel
+// the encoder had in its svt_pme_sad_loop_kernel slot.  Runs under the entries' common lock on the context stream, staging through lane 0's
+// buffer.  Only the part of the MV-rate tables the reference defines travels: nmv_costs[c][MV_VALS] centred on MV_MAX (Codec/mcomp.h) --
+// indices -MV_MAX .. MV_MAX; the two entries a clamp could still reach beyond them read as zero on the device.
 extern "C" void svt_pme_sad_loop_kernel_hip(const SvtHipMvCostParam *mp, uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
                                             uint32_t block_width, uint32_t *best_cost, int16_t *best_mvx, int16_t *best_mvy, int16_t start_x, int16_t start_y, int16_t sa_w,
-                                            int16_t sa_h, int16_t step, int16_t mvx, int16_t mvy) {
-    std::lock_guard<std::mutex> lock(g_pme_leaf_mutex);
-    SvtHipContext *ctx = nullptr;
-    svt_hip_leaf_context(&ctx);
+                                            int16_t sa_h, int16_t step, int16_t mvx, int16_t mvy) LEAF_TRY
+    std::lock_guard<std::mutex> lock(leaf_mutex());
+    SvtHipContext *ctx = leaf_ctx();
     if (sa_w < 8 || sa_h < 1 || block_height == 0 || block_width == 0) return; // no position is visited
     hipSetDevice(ctx->device);
-    auto check = [](hipError_t e, const char *what) {
-        if (e != hipSuccess) { fprintf(stderr, "libsvthip: %s failed in svt_pme_sad_loop_kernel_hip: %s\n", what, hipGetErrorString(e)); abort(); }
-    };
     const int    st = step < 1 ? 1 : step;
     const size_t src_bytes = ((size_t)block_height - 1) * src_stride + block_width;
     const size_t ref_bytes = ((size_t)((sa_h - 1) / st) * st + block_height - 1) * ref_stride + block_width + sa_w + 4;
-    // only the slices of the cost tables the search can index travel: the clamped differences of the visited vectors
-    const int r_lo = -(1 << 14), r_hi = 1 << 14;
-    const bool entropy = mp->mv_cost_type == SVT_HIP_MV_COST_ENTROPY;
+    const int    mv_max = (1 << 14) - 1, r_lo = -(1 << 14), r_hi = 1 << 14; // the table's index range on the device: [r_lo, r_hi]; the host's: [-mv_max, mv_max]
+    const bool   entropy = mp->mv_cost_type == SVT_HIP_MV_COST_ENTROPY;
     const size_t tab = entropy ? (size_t)(r_hi - r_lo + 1) * sizeof(int32_t) : 0;
-    uint8_t *d_all = nullptr;
     const size_t a_src = 0, a_ref = (src_bytes + 255) & ~(size_t)255, a_job = a_ref + ((ref_bytes + 255) & ~(size_t)255), a_out = a_job + 256, a_j = a_out + 256,
                  a_t0 = a_j + 256, a_t1 = a_t0 + ((tab + 255) & ~(size_t)255), total = a_t1 + ((tab + 255) & ~(size_t)255);
-    check(hipMalloc(reinterpret_cast<void **>(&d_all), total), "hipMalloc");
-    check(hipMemcpyAsync(d_all + a_src, src, src_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
-    check(hipMemcpyAsync(d_all + a_ref, ref, ref_bytes - 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync"); // the last 4 bytes are the kernel's dword over-read
+    uint8_t *d_all = leaf_scratch(ctx, total);
+    leaf_check(ctx, hipMemcpyAsync(d_all + a_src, src, src_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_all + a_ref, ref, ref_bytes - 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync"); // the last 4 bytes are the kernel's dword over-read
     SvtHipPmeJob jb;
     memset(&jb, 0, sizeof(jb));
     jb.width = (uint8_t)block_width; jb.height = (uint8_t)block_height; jb.start_x = start_x; jb.start_y = start_y; jb.sa_w = sa_w; jb.sa_h = sa_h; jb.step = step;
     jb.mvx = mvx; jb.mvy = mvy; jb.ref_mv = *mp->ref_mv; jb.best_cost = *best_cost; jb.best_mvx = *best_mvx; jb.best_mvy = *best_mvy;
-    check(hipMemcpyAsync(d_all + a_job, &jb, sizeof(jb), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipMemcpyAsync(d_all + a_job, &jb, sizeof(jb), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
     SvtHipPmeBatchDesc d;
     memset(&d, 0, sizeof(d));
     d.n_jobs = 1; d.src_stride = src_stride; d.ref_stride = ref_stride; d.src = d_all + a_src; d.ref = d_all + a_ref;
     d.jobs = reinterpret_cast<const SvtHipPmeJob *>(d_all + a_job);
     d.mv_cost_type = mp->mv_cost_type; d.error_per_bit = mp->error_per_bit;
     if (entropy) {
-        check(hipMemcpyAsync(d_all + a_j, mp->mvjcost, 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
-        check(hipMemcpyAsync(d_all + a_t0, mp->mvcost[0] + r_lo, tab, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
-        check(hipMemcpyAsync(d_all + a_t1, mp->mvcost[1] + r_lo, tab, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+        leaf_check(ctx, hipMemcpyAsync(d_all + a_j, mp->mvjcost, 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+        for (int c = 0; c < 2; c++) {
+            uint8_t *t = d_all + (c ? a_t1 : a_t0);
+            leaf_check(ctx, hipMemsetAsync(t, 0, tab, ctx->stream), "hipMemsetAsync");
+            leaf_check(ctx, hipMemcpyAsync(t + (size_t)(-mv_max - r_lo) * sizeof(int32_t), mp->mvcost[c] - mv_max, (size_t)(2 * mv_max + 1) * sizeof(int32_t), hipMemcpyHostToDevice,
+                                           ctx->stream), "hipMemcpyAsync");
+        }
         d.mvjcost = reinterpret_cast<const int32_t *>(d_all + a_j);
         d.mvcost[0] = reinterpret_cast<const int32_t *>(d_all + a_t0) - r_lo;
         d.mvcost[1] = reinterpret_cast<const int32_t *>(d_all + a_t1) - r_lo;
     }
     d.best_cost = reinterpret_cast<uint32_t *>(d_all + a_out);
     d.best_mv   = reinterpret_cast<int16_t *>(d_all + a_out + 16);
-    if (svt_hip_pme_sad_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
+    if (svt_hip_pme_sad_batch(ctx, &d) != SVT_HIP_OK) leaf_fail("%s", svt_hip_err_buf());
     struct { uint32_t cost; uint32_t pad[3]; int16_t mv[2]; } out;
-    check(hipMemcpyAsync(&out, d_all + a_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
-    check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    hipFree(d_all);
+    leaf_check(ctx, hipMemcpyAsync(&out, d_all + a_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     *best_cost = out.cost; *best_mvx = out.mv[0]; *best_mvy = out.mv[1];
-}
+LEAF_CATCH(svt_pme_sad_loop_kernel_hip, mp, src, src_stride, ref, ref_stride, block_height, block_width, best_cost, best_mvx, best_mvy, start_x, start_y, sa_w, sa_h, step, mvx, mvy)

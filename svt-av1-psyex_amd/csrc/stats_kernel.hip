@@ -23,8 +23,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
+#include <stdarg.h>
 #include "svt_hip_internal.h"
+#include "leaf_guard.h"
 #include "../../include/svt_hip_spy_rd.h"
 #include "../../include/svt_hip_dsp.h"
 #include "../../include/svt_hip_leaf.h"
@@ -662,9 +665,18 @@ template <typename Pix> __global__ void __launch_bounds__(256) residual_kernel(c
     }
 }
 
-// ---- process-global context of the pointer-level entries -----------------------------------------------------------
+// ---- process-global state of the pointer-level entries -----------------------------------------------------------
 SvtHipContext *g_leaf_ctx = nullptr;
 std::mutex     g_leaf_mutex; // the reference calls its kernels from many threads; these entries serialise on one stream
+// previous kernels of the slots svt_hip_install_rtcd wrote to, by this library's symbol name
+struct LeafPrev { char symbol[96]; void *prev; void **slot; };
+LeafPrev   g_leaf_prev[640];
+int        g_leaf_nprev = 0;
+std::mutex g_leaf_prev_mutex;
+std::atomic<unsigned long long> g_leaf_fallbacks{0}, g_leaf_unhandled{0};
+std::atomic<int>                g_leaf_inject{0};
+char       g_leaf_msg[SVT_HIP_ERR_BYTES] = "";
+thread_local int t_leaf_depth = 0;
 
 } // namespace
 
@@ -695,21 +707,10 @@ int svt_hip_leaf_bind(SvtHipContext *ctx) {
     return SVT_HIP_OK;
 }
 
-// for the pointer-level entries that live in other files (pme_kernel.hip)
-int svt_hip_leaf_context(SvtHipContext **out) {
-    std::lock_guard<std::mutex> lock(g_leaf_mutex);
-    if (!g_leaf_ctx) {
-        fprintf(stderr, "libsvthip: a _hip leaf kernel was called before svt_hip_leaf_bind(); there is no CPU fallback\n");
-        abort();
-    }
-    *out = g_leaf_ctx;
-    return SVT_HIP_OK;
-}
-
 // The `_hip` entry that takes the place of the reference's function pointer `name`: the exported symbol <name>_hip of this library
 // (the pointer-level entries carry the reference's pointer names), or the one the short alias table names where the reference's
 // pointer and its `_c` body are called differently.
-const void *svt_hip_rtcd_lookup(const char *name) {
+static const void *rtcd_lookup_symbol(const char *name, char *sym, size_t sym_bytes) {
     static const struct { const char *pointer, *symbol; } alias[] = {
         {"svt_nxm_sad_kernel", "svt_nxm_sad_kernel_helper_hip"},          // aom_dsp_rtcd.h:125 -> svt_nxm_sad_kernel_helper_c
         {"svt_aom_quantize_b", "svt_aom_quantize_b_hip"},                 // -> svt_aom_quantize_b_c_ii
@@ -720,66 +721,146 @@ const void *svt_hip_rtcd_lookup(const char *name) {
     if (!dladdr(reinterpret_cast<const void *>(&svt_hip_leaf_bind), &info) || !info.dli_fname) return nullptr;
     void *self = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
     if (!self) return nullptr;
-    char sym[256];
-    snprintf(sym, sizeof(sym), "%s_hip", name);
+    snprintf(sym, sym_bytes, "%s_hip", name);
     for (const auto &a : alias)
-        if (!strcmp(a.pointer, name)) snprintf(sym, sizeof(sym), "%s", a.symbol);
+        if (!strcmp(a.pointer, name)) snprintf(sym, sym_bytes, "%s", a.symbol);
     const void *fn = dlsym(self, sym);
     dlclose(self);
     return fn;
+}
+const void *svt_hip_rtcd_lookup(const char *name) {
+    char sym[256];
+    return rtcd_lookup_symbol(name, sym, sizeof(sym));
+}
+
+// Stores this library's entries into the slots and keeps what each slot held before -- the encoder's own kernel -- as the entry's way
+// out: a `_hip` entry that cannot run (no bound context, a device error) calls it with the same arguments (leaf_guard.h).  No context is
+// bound: until svt_hip_leaf_bind() every call goes to the previous kernels.
+int svt_hip_rtcd_store(const SvtHipRtcdSlot *slots, uint32_t n_slots, uint32_t *n_skipped) {
+    if (!slots && n_slots) return SVT_HIP_ERR_BAD_PARAM;
+    uint32_t skipped = 0;
+    for (uint32_t i = 0; i < n_slots; i++)
+        if (!slots[i].slot) return svt_hip_fail(nullptr, SVT_HIP_ERR_BAD_PARAM, "rtcd slot %u (%s): null address", i, slots[i].name ? slots[i].name : "?");
+    std::lock_guard<std::mutex> lock(g_leaf_prev_mutex);
+    for (uint32_t i = 0; i < n_slots; i++) {
+        char sym[256];
+        const void *fn = rtcd_lookup_symbol(slots[i].name, sym, sizeof(sym));
+        if (!fn) { skipped++; continue; }
+        void *prev = *slots[i].slot;
+        if (prev == fn) continue; // installed already: keep the previous kernel recorded then
+        int k = 0;
+        while (k < g_leaf_nprev && strcmp(g_leaf_prev[k].symbol, sym)) k++;
+        if (k == g_leaf_nprev) {
+            if (g_leaf_nprev == (int)(sizeof(g_leaf_prev) / sizeof(g_leaf_prev[0]))) return svt_hip_fail(nullptr, SVT_HIP_ERR_NO_MEMORY, "rtcd: too many slots");
+            snprintf(g_leaf_prev[k].symbol, sizeof(g_leaf_prev[k].symbol), "%s", sym);
+            g_leaf_nprev++;
+        }
+        g_leaf_prev[k].prev = prev;
+        g_leaf_prev[k].slot = slots[i].slot;
+        *slots[i].slot = const_cast<void *>(fn);
+    }
+    if (n_skipped) *n_skipped = skipped;
+    return SVT_HIP_OK;
 }
 
 // What svt_aom_setup_rtcd_internal (Codec/aom_dsp_rtcd.c:188, called at Globals/enc_handle.c:1444-1445) does for a SIMD flavour: assign
 // this backend's entries into the encoder's function pointers.  `slots[i].slot` is the ADDRESS of the encoder's pointer variable
 // `slots[i].name`.  Names this library has no entry for are left as they are (the encoder keeps its own kernel there) and counted in
-// *n_skipped.  Binds `ctx` for the pointer-level entries (they have no context argument).  Call it before init_fn_ptr()
-// (Codec/av1me.c:31, enc_handle.c:1460), which copies pointer VALUES into svt_aom_mefn_ptr[].
+// *n_skipped.  Binds `ctx` for the pointer-level entries (they have no context argument).  Without a context nothing is touched: the
+// encoder keeps its dispatch.  Call it before init_fn_ptr() (Codec/av1me.c:31, enc_handle.c:1460), which copies pointer VALUES into
+// svt_aom_mefn_ptr[].
 int svt_hip_install_rtcd(SvtHipContext *ctx, const SvtHipRtcdSlot *slots, uint32_t n_slots, uint32_t *n_skipped) {
     if (!ctx || (!slots && n_slots)) return SVT_HIP_ERR_BAD_PARAM;
-    uint32_t skipped = 0;
-    for (uint32_t i = 0; i < n_slots; i++) {
-        if (!slots[i].slot) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "rtcd slot %u (%s): null address", i, slots[i].name ? slots[i].name : "?");
-        const void *fn = svt_hip_rtcd_lookup(slots[i].name);
-        if (!fn) { skipped++; continue; }
-        *slots[i].slot = const_cast<void *>(fn);
-    }
-    if (n_skipped) *n_skipped = skipped;
+    if (int rc = svt_hip_rtcd_store(slots, n_slots, n_skipped)) return rc;
     return svt_hip_leaf_bind(ctx);
 }
+
+// Puts the previous kernels back into the slots svt_hip_install_rtcd / svt_hip_rtcd_store wrote to (an encoder that gives the device up).
+int svt_hip_uninstall_rtcd(const SvtHipRtcdSlot *slots, uint32_t n_slots) {
+    if (!slots && n_slots) return SVT_HIP_ERR_BAD_PARAM;
+    std::lock_guard<std::mutex> lock(g_leaf_prev_mutex);
+    for (uint32_t i = 0; i < n_slots; i++) {
+        if (!slots[i].slot) continue;
+        for (int k = 0; k < g_leaf_nprev; k++)
+            if (g_leaf_prev[k].slot == slots[i].slot && g_leaf_prev[k].prev) { *slots[i].slot = g_leaf_prev[k].prev; break; }
+    }
+    return SVT_HIP_OK;
+}
+
+// Calls the previous kernels served since the last call (`fallbacks`), calls that failed with no previous kernel to go to (`unhandled`:
+// their outputs are zero / untouched), and the last failure's text.  Any pointer may be null.  Returns the sum of both counts (saturated).
+int svt_hip_leaf_status(unsigned long long *fallbacks, unsigned long long *unhandled, char *message, size_t message_bytes) {
+    const unsigned long long f = g_leaf_fallbacks.exchange(0), u = g_leaf_unhandled.exchange(0);
+    if (fallbacks) *fallbacks = f;
+    if (unhandled) *unhandled = u;
+    if (message && message_bytes) {
+        std::lock_guard<std::mutex> lock(g_leaf_prev_mutex);
+        snprintf(message, message_bytes, "%s", g_leaf_msg);
+    }
+    return (int)((f + u) > 0x7fffffffull ? 0x7fffffff : (f + u));
+}
+
+// Testing aid: while on, every pointer-level entry behaves as if the device had failed.
+void svt_hip_leaf_inject_failure(int on) { g_leaf_inject.store(on ? 1 : 0); }
 
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------
 // Pointer-level entries: host pointers in, host results out, synchronous.  Each call stages the few rows it
 // needs into the context's scratch buffer, launches, and copies the result back -- a validation / drop-in path,
-// three PCIe round trips per call; production goes through the batched entries.  Without a bound context the
-// process aborts: there is no CPU fallback behind these symbols.
+// three PCIe round trips per call; production goes through the batched entries.  An entry that cannot run (no bound context, a
+// device error) hands the call to the kernel the encoder had in the slot before the installer (leaf_guard.h): fail closed, never abort.
 // ---------------------------------------------------------------------------------------------------------
-namespace {
-
+// (leaf_guard.h) the helpers of the pointer-level entries: failures throw, the entry's handler hands the call to the previous kernel
+[[noreturn]] void leaf_fail(const char *fmt, ...) {
+    LeafFailure f;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(f.what, sizeof(f.what), fmt, ap);
+    va_end(ap);
+    throw f;
+}
 SvtHipContext *leaf_ctx() {
-    if (!g_leaf_ctx) {
-        fprintf(stderr, "libsvthip: a _hip leaf kernel was called before svt_hip_leaf_bind(); there is no CPU fallback\n");
-        abort();
-    }
+    if (g_leaf_inject.load()) leaf_fail("injected failure (svt_hip_leaf_inject_failure)");
+    if (!g_leaf_ctx) leaf_fail("a _hip leaf kernel was called with no context bound (svt_hip_leaf_bind / svt_hip_install_rtcd)");
     return g_leaf_ctx;
 }
-
-void leaf_check(SvtHipContext *ctx, hipError_t e, const char *what) {
-    if (e != hipSuccess) {
-        fprintf(stderr, "libsvthip: %s failed in a _hip leaf kernel: %s\n", what, hipGetErrorString(e));
-        (void)ctx;
-        abort(); // the reference's leaf kernels have no error channel
-    }
+void leaf_check(SvtHipContext *, hipError_t e, const char *what) {
+    if (e != hipSuccess) leaf_fail("%s failed in a _hip leaf kernel: %s", what, hipGetErrorString(e));
 }
-
-// device staging area: [0, bytes) carved by the caller.  The pointer-level entries run one at a time (g_leaf_mutex) on the context
+// device staging area: [0, bytes) carved by the caller.  The pointer-level entries run one at a time (leaf_mutex) on the context
 // stream; lane 0's result buffer is theirs alone (the asynchronous entries use none, the synchronous ones borrow other lanes).
 uint8_t *leaf_scratch(SvtHipContext *ctx, size_t bytes) {
     void *pp = nullptr;
-    if (svt_hip_scratch(ctx, &ctx->lane[0], bytes, &pp) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: out of device memory in a _hip leaf kernel\n"); abort(); }
+    if (svt_hip_scratch(ctx, &ctx->lane[0], bytes, &pp) != SVT_HIP_OK) leaf_fail("out of device memory in a _hip leaf kernel (%zu bytes)", bytes);
     return static_cast<uint8_t *>(pp);
 }
+std::mutex &leaf_mutex() { return g_leaf_mutex; }
+int         leaf_depth() { return t_leaf_depth; }
+LeafEnter::LeafEnter() { t_leaf_depth++; }
+LeafEnter::~LeafEnter() { t_leaf_depth--; }
+const void *leaf_previous(const char *symbol) {
+    std::lock_guard<std::mutex> lock(g_leaf_prev_mutex);
+    for (int k = 0; k < g_leaf_nprev; k++)
+        if (!strcmp(g_leaf_prev[k].symbol, symbol)) return g_leaf_prev[k].prev;
+    return nullptr;
+}
+static void leaf_note(const char *symbol, const LeafFailure &f, const char *how) {
+    std::lock_guard<std::mutex> lock(g_leaf_prev_mutex);
+    snprintf(g_leaf_msg, sizeof(g_leaf_msg), "%s: %s -- %s", symbol, f.what, how);
+    snprintf(svt_hip_err_buf(), SVT_HIP_ERR_BYTES, "%s", g_leaf_msg); // svt_hip_last_error() of the calling thread
+}
+void leaf_note_fallback(const char *symbol, const LeafFailure &f) {
+    g_leaf_fallbacks++;
+    leaf_note(symbol, f, "the call went to the kernel the encoder had installed before");
+}
+void leaf_note_unhandled(const char *symbol, const LeafFailure &f) {
+    g_leaf_unhandled++;
+    leaf_note(symbol, f, "no previous kernel is known for this entry: nothing was computed");
+    fprintf(stderr, "libsvthip: %s\n", g_leaf_msg);
+}
+
+namespace {
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -816,7 +897,7 @@ StatsOut leaf_stats(const void *src, size_t src_stride, const void *ref, size_t 
     d.sad = &o->sad; d.variance = &o->variance; d.var_sse = &o->var_sse; d.sse = reinterpret_cast<uint64_t *>(&o->sse); d.satd = want_satd ? &o->satd : nullptr;
     if (bit_depth == 10) { d.variance10 = &o->variance10; d.var_sse10 = &o->var_sse10; }
     if (want_psy) { d.psy_rd = psy_rd; d.psy_energy = reinterpret_cast<uint64_t *>(&o->psy_energy); d.psy_dist = reinterpret_cast<uint64_t *>(&o->psy_dist); }
-    if (svt_hip_block_stats_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
+    if (svt_hip_block_stats_batch(ctx, &d) != SVT_HIP_OK) leaf_fail("%s", svt_hip_err_buf());
     StatsOut out;
     memset(&out, 0, sizeof(out));
     leaf_check(ctx, hipMemcpyAsync(&out, d_out, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
@@ -830,7 +911,7 @@ extern "C" {
 
 void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t block_height,
                              uint32_t block_width, uint64_t *best_sad, int16_t *x_search_center, int16_t *y_search_center,
-                             uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height) {
+                             uint32_t src_stride_raw, uint8_t skip_search_line, int16_t search_area_width, int16_t search_area_height) LEAF_TRY
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
@@ -862,63 +943,63 @@ void svt_sad_loop_kernel_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, ui
         *x_search_center = (int16_t)(best & 0xFFFF);
         *y_search_center = (int16_t)((best >> 16) & 0xFFFF);
     }
-}
+LEAF_CATCH(svt_sad_loop_kernel_hip, src, src_stride, ref, ref_stride, block_height, block_width, best_sad, x_search_center, y_search_center, src_stride_raw, skip_search_line, search_area_width, search_area_height)
 
-uint32_t svt_nxm_sad_kernel_helper_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
+uint32_t svt_nxm_sad_kernel_helper_hip(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) LEAF_TRY
     return leaf_stats(src, src_stride, ref, ref_stride, (int)width, (int)height, 8, false).sad;
-}
+LEAF_CATCH(svt_nxm_sad_kernel_helper_hip, src, src_stride, ref, ref_stride, height, width)
 
-uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) {
+uint32_t svt_aom_sad_16b_kernel_hip(uint16_t *src, uint32_t src_stride, uint16_t *ref, uint32_t ref_stride, uint32_t height, uint32_t width) LEAF_TRY
     return leaf_stats(src, src_stride, ref, ref_stride, (int)width, (int)height, 10, false).sad;
-}
+LEAF_CATCH(svt_aom_sad_16b_kernel_hip, src, src_stride, ref, ref_stride, height, width)
 
-unsigned int svt_aom_variance_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int width, int height, unsigned int *sse) {
+unsigned int svt_aom_variance_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int width, int height, unsigned int *sse) LEAF_TRY
     const StatsOut o = leaf_stats(src, (size_t)src_stride, ref, (size_t)ref_stride, width, height, 8, false);
     *sse = o.var_sse;
     return o.variance;
-}
+LEAF_CATCH(svt_aom_variance_hip, src, src_stride, ref, ref_stride, width, height, sse)
 
 unsigned int svt_aom_sub_pixel_variance_hip(const uint8_t *src, int src_stride, int xoffset, int yoffset, const uint8_t *ref, int ref_stride, int width,
-                                            int height, unsigned int *sse) {
+                                            int height, unsigned int *sse) LEAF_TRY
     const StatsOut o = leaf_stats(src, (size_t)src_stride, ref, (size_t)ref_stride, width, height, 8, false, false, 0.0, xoffset & 7, yoffset & 7);
     *sse = o.var_sse;
     return o.variance;
-}
+LEAF_CATCH(svt_aom_sub_pixel_variance_hip, src, src_stride, xoffset, yoffset, ref, ref_stride, width, height, sse)
 
 #define SVT_HIP_VAR(W, H)                                                                                                             \
-    unsigned int svt_aom_variance##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, unsigned int *sse) { \
+    unsigned int svt_aom_variance##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, unsigned int *sse) LEAF_TRY \
         return svt_aom_variance_hip(src, src_stride, ref, ref_stride, W, H, sse);                                                       \
-    }                                                                                                                                 \
+    LEAF_CATCH(svt_aom_variance##W##x##H##_hip, src, src_stride, ref, ref_stride, sse)                                                  \
     unsigned int svt_aom_sub_pixel_variance##W##x##H##_hip(const uint8_t *src, int src_stride, int xoffset, int yoffset, const uint8_t *ref, \
-                                                           int ref_stride, unsigned int *sse) {                                      \
+                                                           int ref_stride, unsigned int *sse) LEAF_TRY                               \
         return svt_aom_sub_pixel_variance_hip(src, src_stride, xoffset, yoffset, ref, ref_stride, W, H, sse);                           \
-    }
+    LEAF_CATCH(svt_aom_sub_pixel_variance##W##x##H##_hip, src, src_stride, xoffset, yoffset, ref, ref_stride, sse)
 SVT_HIP_VAR(4, 4) SVT_HIP_VAR(4, 8) SVT_HIP_VAR(4, 16) SVT_HIP_VAR(8, 4) SVT_HIP_VAR(8, 8) SVT_HIP_VAR(8, 16) SVT_HIP_VAR(8, 32)
 SVT_HIP_VAR(16, 4) SVT_HIP_VAR(16, 8) SVT_HIP_VAR(16, 16) SVT_HIP_VAR(16, 32) SVT_HIP_VAR(16, 64) SVT_HIP_VAR(32, 8) SVT_HIP_VAR(32, 16)
 SVT_HIP_VAR(32, 32) SVT_HIP_VAR(32, 64) SVT_HIP_VAR(64, 16) SVT_HIP_VAR(64, 32) SVT_HIP_VAR(64, 64) SVT_HIP_VAR(64, 128) SVT_HIP_VAR(128, 64)
 SVT_HIP_VAR(128, 128)
 #undef SVT_HIP_VAR
 
-int64_t svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height) {
+int64_t svt_aom_sse_hip(const uint8_t *a, int a_stride, const uint8_t *b, int b_stride, int width, int height) LEAF_TRY
     return (int64_t)leaf_stats(a, (size_t)a_stride, b, (size_t)b_stride, width, height, 8, false).sse;
-}
+LEAF_CATCH(svt_aom_sse_hip, a, a_stride, b, b_stride, width, height)
 
 // svt_aom_highbd_sse (aom_dsp_rtcd.h:56; enc_inter_prediction.c:559-570): the uint8_t pointers ARE the uint16_t pointers (plain cast there)
-int64_t svt_aom_highbd_sse_hip(const uint8_t *a8, int a_stride, const uint8_t *b8, int b_stride, int width, int height) {
+int64_t svt_aom_highbd_sse_hip(const uint8_t *a8, int a_stride, const uint8_t *b8, int b_stride, int width, int height) LEAF_TRY
     return (int64_t)leaf_stats(reinterpret_cast<const uint16_t *>(a8), (size_t)a_stride, reinterpret_cast<const uint16_t *>(b8), (size_t)b_stride, width, height, 10,
                                false).sse;
-}
+LEAF_CATCH(svt_aom_highbd_sse_hip, a8, a_stride, b8, b_stride, width, height)
 
 uint64_t svt_spatial_full_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
-                                                uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
+                                                uint32_t recon_stride, uint32_t area_width, uint32_t area_height) LEAF_TRY
     return leaf_stats(input + input_offset, input_stride, recon + recon_offset, recon_stride, (int)area_width, (int)area_height, 8, false).sse;
-}
+LEAF_CATCH(svt_spatial_full_distortion_kernel_hip, input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height)
 
 uint64_t svt_full_distortion_kernel16_bits_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
-                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height) {
+                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height) LEAF_TRY
     return leaf_stats(reinterpret_cast<uint16_t *>(input) + input_offset, input_stride, reinterpret_cast<uint16_t *>(recon) + recon_offset, recon_stride,
                       (int)area_width, (int)area_height, 10, false).sse;
-}
+LEAF_CATCH(svt_full_distortion_kernel16_bits_hip, input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height)
 
 uint64_t svt_hip_spy_rd_bias(uint64_t sse, uint32_t area_width, uint32_t area_height, uint8_t mode, uint8_t compound_type, uint8_t temporal_layer_index,
                              double psy_rd, uint8_t spy_rd) {
@@ -927,35 +1008,35 @@ uint64_t svt_hip_spy_rd_bias(uint64_t sse, uint32_t area_width, uint32_t area_he
 
 uint64_t svt_spatial_full_distortion_kernel_facade_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
                                                        uint32_t recon_stride, uint32_t area_width, uint32_t area_height, bool hbd_md, uint8_t mode,
-                                                       uint8_t compound_type, uint8_t temporal_layer_index, double psy_rd, uint8_t spy_rd) {
+                                                       uint8_t compound_type, uint8_t temporal_layer_index, double psy_rd, uint8_t spy_rd) LEAF_TRY
     const uint64_t sse = hbd_md ? svt_full_distortion_kernel16_bits_hip(input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height)
                                 : svt_spatial_full_distortion_kernel_hip(input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height);
     return svt_hip_spy_rd_bias(sse, area_width, area_height, mode, compound_type, temporal_layer_index, psy_rd, spy_rd);
-}
+LEAF_CATCH(svt_spatial_full_distortion_kernel_facade_hip, input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height, hbd_md, mode, compound_type, temporal_layer_index, psy_rd, spy_rd)
 
 uint64_t svt_spatial_psy_distortion_kernel_hip(uint8_t *input, uint32_t input_offset, uint32_t input_stride, uint8_t *recon, int32_t recon_offset,
-                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height, double psy_rd) {
+                                               uint32_t recon_stride, uint32_t area_width, uint32_t area_height, double psy_rd) LEAF_TRY
     const StatsOut o = leaf_stats(input + input_offset, input_stride, recon + recon_offset, recon_stride, (int)area_width, (int)area_height, 8, false,
                                   psy_rd > 0.0, psy_rd);
     return o.sse + (psy_rd > 0.0 ? o.psy_dist : 0);
-}
+LEAF_CATCH(svt_spatial_psy_distortion_kernel_hip, input, input_offset, input_stride, recon, recon_offset, recon_stride, area_width, area_height, psy_rd)
 
-uint64_t svt_psy_distortion_hip(const uint8_t *input, uint32_t input_stride, const uint8_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height) {
+uint64_t svt_psy_distortion_hip(const uint8_t *input, uint32_t input_stride, const uint8_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height) LEAF_TRY
     return leaf_stats(input, input_stride, recon, recon_stride, (int)width, (int)height, 8, false, true, 0.0).psy_energy;
-}
-uint64_t svt_psy_distortion_hbd_hip(const uint16_t *input, uint32_t input_stride, const uint16_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height) {
+LEAF_CATCH(svt_psy_distortion_hip, input, input_stride, recon, recon_stride, width, height)
+uint64_t svt_psy_distortion_hbd_hip(const uint16_t *input, uint32_t input_stride, const uint16_t *recon, uint32_t recon_stride, uint32_t width, uint32_t height) LEAF_TRY
     return leaf_stats(input, input_stride, recon, recon_stride, (int)width, (int)height, 10, false, true, 0.0).psy_energy;
-}
+LEAF_CATCH(svt_psy_distortion_hbd_hip, input, input_stride, recon, recon_stride, width, height)
 uint64_t get_svt_psy_full_dist_hip(const void *s, uint32_t so, uint32_t sp, const void *r, uint32_t ro, uint32_t rp, uint32_t w, uint32_t h, uint8_t is_hbd,
-                                   double psy_rd) {
+                                   double psy_rd) LEAF_TRY
     if (is_hbd == 1)
         return leaf_stats(static_cast<const uint16_t *>(s) + so, sp, static_cast<const uint16_t *>(r) + ro, rp, (int)w, (int)h, 10, false, true, psy_rd).psy_dist;
     return leaf_stats(static_cast<const uint8_t *>(s) + so, sp, static_cast<const uint8_t *>(r) + ro, rp, (int)w, (int)h, 8, false, true, psy_rd).psy_dist;
-}
+LEAF_CATCH(get_svt_psy_full_dist_hip, s, so, sp, r, ro, rp, w, h, is_hbd, psy_rd)
 
-uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide) {
+uint32_t svt_hip_hadamard_path(const uint8_t *input, uint32_t input_stride, const uint8_t *pred, uint32_t pred_stride, uint32_t block_size_wide) LEAF_TRY
     return leaf_stats(input, input_stride, pred, pred_stride, (int)block_size_wide, (int)block_size_wide, 8, true).satd;
-}
+LEAF_CATCH(svt_hip_hadamard_path, input, input_stride, pred, pred_stride, block_size_wide)
 
 static void leaf_hadamard(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff, int n) {
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
@@ -969,12 +1050,12 @@ static void leaf_hadamard(const int16_t *src_diff, ptrdiff_t src_stride, int32_t
     leaf_check(ctx, hipMemcpyAsync(coeff, base + sb, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
-void svt_aom_hadamard_4x4_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 4); }
-void svt_aom_hadamard_8x8_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 8); }
-void svt_aom_hadamard_16x16_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 16); }
-void svt_aom_hadamard_32x32_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) { leaf_hadamard(src_diff, src_stride, coeff, 32); }
+void svt_aom_hadamard_4x4_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) LEAF_TRY leaf_hadamard(src_diff, src_stride, coeff, 4); LEAF_CATCH(svt_aom_hadamard_4x4_hip, src_diff, src_stride, coeff)
+void svt_aom_hadamard_8x8_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) LEAF_TRY leaf_hadamard(src_diff, src_stride, coeff, 8); LEAF_CATCH(svt_aom_hadamard_8x8_hip, src_diff, src_stride, coeff)
+void svt_aom_hadamard_16x16_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) LEAF_TRY leaf_hadamard(src_diff, src_stride, coeff, 16); LEAF_CATCH(svt_aom_hadamard_16x16_hip, src_diff, src_stride, coeff)
+void svt_aom_hadamard_32x32_hip(const int16_t *src_diff, ptrdiff_t src_stride, int32_t *coeff) LEAF_TRY leaf_hadamard(src_diff, src_stride, coeff, 32); LEAF_CATCH(svt_aom_hadamard_32x32_hip, src_diff, src_stride, coeff)
 
-int svt_aom_satd_hip(const int32_t *coeff, int length) {
+int svt_aom_satd_hip(const int32_t *coeff, int length) LEAF_TRY
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
@@ -988,11 +1069,11 @@ int svt_aom_satd_hip(const int32_t *coeff, int length) {
     leaf_check(ctx, hipMemcpyAsync(&out, base + cb, sizeof(out), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return out;
-}
+LEAF_CATCH(svt_aom_satd_hip, coeff, length)
 
 // svt_av1_compute_cul_level (aom_dsp_rtcd.h:904): the prototype carries no array length; scan[0 .. eob) and the coefficients those
 // positions (and position 0) name are what the reference reads, so that is what travels
-uint8_t svt_av1_compute_cul_level_hip(const int16_t *const scan, const int32_t *const quant_coeff, uint16_t *eob) {
+uint8_t svt_av1_compute_cul_level_hip(const int16_t *const scan, const int32_t *const quant_coeff, uint16_t *eob) LEAF_TRY
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
@@ -1009,10 +1090,10 @@ uint8_t svt_av1_compute_cul_level_hip(const int16_t *const scan, const int32_t *
     leaf_check(ctx, hipMemcpyAsync(&out, base + sb + qb, 1, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return out;
-}
+LEAF_CATCH(svt_av1_compute_cul_level_hip, scan, quant_coeff, eob)
 
 // svt_av1_fwht4x4 (aom_dsp_rtcd.h:208)
-void svt_av1_fwht4x4_hip(int16_t *input, int32_t *output, uint32_t stride) {
+void svt_av1_fwht4x4_hip(int16_t *input, int32_t *output, uint32_t stride) LEAF_TRY
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
@@ -1023,7 +1104,7 @@ void svt_av1_fwht4x4_hip(int16_t *input, int32_t *output, uint32_t stride) {
     leaf_check(ctx, hipGetLastError(), "fwht4x4_kernel launch");
     leaf_check(ctx, hipMemcpyAsync(output, base + ib, 16 * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-}
+LEAF_CATCH(svt_av1_fwht4x4_hip, input, output, stride)
 
 // get_hvs_modulation_factor (psy_rd.c:295-307): host arithmetic
 double svt_hip_hvs_modulation_factor(double psy_rd, int is_islice, uint8_t temporal_layer_index) {
@@ -1037,12 +1118,12 @@ double svt_hip_hvs_modulation_factor(double psy_rd, int is_islice, uint8_t tempo
 
 // svt_aom_sad{W}x{H} and the four-reference form (aom_dsp_rtcd.h:267-347; macros at C_DEFAULT/compute_sad_c.c:117-207)
 #define SVT_HIP_SAD(W, H)                                                                                                              \
-    uint32_t svt_aom_sad##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride) {                     \
+    uint32_t svt_aom_sad##W##x##H##_hip(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride) LEAF_TRY              \
         return leaf_stats(src, (size_t)src_stride, ref, (size_t)ref_stride, W, H, 8, false).sad;                                        \
-    }                                                                                                                                  \
-    void svt_aom_sad##W##x##H##x4d_hip(const uint8_t *src, int src_stride, const uint8_t *const ref[], int ref_stride, uint32_t *sad_array) { \
+    LEAF_CATCH(svt_aom_sad##W##x##H##_hip, src, src_stride, ref, ref_stride)                                                           \
+    void svt_aom_sad##W##x##H##x4d_hip(const uint8_t *src, int src_stride, const uint8_t *const ref[], int ref_stride, uint32_t *sad_array) LEAF_TRY \
         for (int i = 0; i < 4; i++) sad_array[i] = leaf_stats(src, (size_t)src_stride, ref[i], (size_t)ref_stride, W, H, 8, false).sad; \
-    }
+    LEAF_CATCH(svt_aom_sad##W##x##H##x4d_hip, src, src_stride, ref, ref_stride, sad_array)
 SVT_HIP_SAD(4, 4) SVT_HIP_SAD(4, 8) SVT_HIP_SAD(4, 16) SVT_HIP_SAD(8, 4) SVT_HIP_SAD(8, 8) SVT_HIP_SAD(8, 16) SVT_HIP_SAD(8, 32)
 SVT_HIP_SAD(16, 4) SVT_HIP_SAD(16, 8) SVT_HIP_SAD(16, 16) SVT_HIP_SAD(16, 32) SVT_HIP_SAD(16, 64) SVT_HIP_SAD(32, 8) SVT_HIP_SAD(32, 16)
 SVT_HIP_SAD(32, 32) SVT_HIP_SAD(32, 64) SVT_HIP_SAD(64, 16) SVT_HIP_SAD(64, 32) SVT_HIP_SAD(64, 64) SVT_HIP_SAD(64, 128) SVT_HIP_SAD(128, 64)
@@ -1051,23 +1132,23 @@ SVT_HIP_SAD(128, 128)
 
 // svt_aom_highbd_10_variance{W}x{H} (aom_dsp_rtcd.h:546-568): the uint8_t pointers carry uint16_t addresses >> 1 (CONVERT_TO_SHORTPTR)
 #define SVT_HIP_VAR10(W, H)                                                                                                           \
-    unsigned int svt_aom_highbd_10_variance##W##x##H##_hip(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, unsigned int *sse) { \
+    unsigned int svt_aom_highbd_10_variance##W##x##H##_hip(const uint8_t *src8, int src_stride, const uint8_t *ref8, int ref_stride, unsigned int *sse) LEAF_TRY \
         const StatsOut o = leaf_stats(reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(src8) << 1), (size_t)src_stride,  \
                                       reinterpret_cast<const uint16_t *>(reinterpret_cast<uintptr_t>(ref8) << 1), (size_t)ref_stride, W, H, 10, false); \
         *sse = o.var_sse10;                                                                                                            \
         return o.variance10;                                                                                                           \
-    }
+    LEAF_CATCH(svt_aom_highbd_10_variance##W##x##H##_hip, src8, src_stride, ref8, ref_stride, sse)
 SVT_HIP_VAR10(4, 4) SVT_HIP_VAR10(4, 8) SVT_HIP_VAR10(4, 16) SVT_HIP_VAR10(8, 4) SVT_HIP_VAR10(8, 8) SVT_HIP_VAR10(8, 16) SVT_HIP_VAR10(8, 32)
 SVT_HIP_VAR10(16, 4) SVT_HIP_VAR10(16, 8) SVT_HIP_VAR10(16, 16) SVT_HIP_VAR10(16, 32) SVT_HIP_VAR10(16, 64) SVT_HIP_VAR10(32, 8) SVT_HIP_VAR10(32, 16)
 SVT_HIP_VAR10(32, 32) SVT_HIP_VAR10(32, 64) SVT_HIP_VAR10(64, 16) SVT_HIP_VAR10(64, 32) SVT_HIP_VAR10(64, 64) SVT_HIP_VAR10(64, 128) SVT_HIP_VAR10(128, 64)
 SVT_HIP_VAR10(128, 128)
 #undef SVT_HIP_VAR10
 
-uint32_t svt_aom_variance_highbd_hip(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse) {
+uint32_t svt_aom_variance_highbd_hip(const uint16_t *a, int a_stride, const uint16_t *b, int b_stride, int w, int h, uint32_t *sse) LEAF_TRY
     const StatsOut o = leaf_stats(a, (size_t)a_stride, b, (size_t)b_stride, w, h, 10, false);
     *sse = o.var_sse;
     return o.variance;
-}
+LEAF_CATCH(svt_aom_variance_highbd_hip, a, a_stride, b, b_stride, w, h, sse)
 
 static void leaf_coeff_dist(const int32_t *coeff, uint32_t cstride, const int32_t *recon, uint32_t rstride, uint32_t w, uint32_t h, uint64_t out[2], int wrap32 = 0) {
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
@@ -1089,21 +1170,21 @@ static void leaf_coeff_dist(const int32_t *coeff, uint32_t cstride, const int32_
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
 void svt_full_distortion_kernel32_bits_hip(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff, uint32_t recon_coeff_stride, uint64_t distortion_result[2],
-                                           uint32_t area_width, uint32_t area_height) {
+                                           uint32_t area_width, uint32_t area_height) LEAF_TRY
     leaf_coeff_dist(coeff, coeff_stride, recon_coeff, recon_coeff_stride, area_width, area_height, distortion_result);
-}
-void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) {
+LEAF_CATCH(svt_full_distortion_kernel32_bits_hip, coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height)
+void svt_full_distortion_kernel_cbf_zero32_bits_hip(int32_t *coeff, uint32_t coeff_stride, uint64_t distortion_result[2], uint32_t area_width, uint32_t area_height) LEAF_TRY
     uint64_t o[2];
     leaf_coeff_dist(coeff, coeff_stride, nullptr, 0, area_width, area_height, o);
     distortion_result[0] = o[1]; // DIST_CALC_RESIDUAL = DIST_CALC_PREDICTION = sum coeff^2 (pic_operators.c:202-222)
     distortion_result[1] = o[1];
-}
-int64_t svt_av1_block_error_hip(const int32_t *coeff, const int32_t *dqcoeff, intptr_t block_size, int64_t *ssz) {
+LEAF_CATCH(svt_full_distortion_kernel_cbf_zero32_bits_hip, coeff, coeff_stride, distortion_result, area_width, area_height)
+int64_t svt_av1_block_error_hip(const int32_t *coeff, const int32_t *dqcoeff, intptr_t block_size, int64_t *ssz) LEAF_TRY
     uint64_t o[2];
     leaf_coeff_dist(coeff, (uint32_t)block_size, dqcoeff, (uint32_t)block_size, (uint32_t)block_size, 1, o, 1);
     *ssz = (int64_t)o[1];
     return (int64_t)o[0];
-}
+LEAF_CATCH(svt_av1_block_error_hip, coeff, dqcoeff, block_size, ssz)
 
 } // extern "C"
 template <typename Pix> static void leaf_residual(const Pix *in, uint32_t in_stride, const Pix *pred, uint32_t pred_stride, int16_t *res, uint32_t res_stride, uint32_t w, uint32_t h) {
@@ -1127,19 +1208,20 @@ template <typename Pix> static void leaf_residual(const Pix *in, uint32_t in_str
 }
 extern "C" {
 void svt_residual_kernel8bit_hip(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
-                                 uint32_t area_width, uint32_t area_height) {
+                                 uint32_t area_width, uint32_t area_height) LEAF_TRY
     leaf_residual<uint8_t>(input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height);
-}
+LEAF_CATCH(svt_residual_kernel8bit_hip, input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height)
 void svt_residual_kernel16bit_hip(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride, int16_t *residual, uint32_t residual_stride,
-                                  uint32_t area_width, uint32_t area_height) {
+                                  uint32_t area_width, uint32_t area_height) LEAF_TRY
     leaf_residual<uint16_t>(input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height);
-}
+LEAF_CATCH(svt_residual_kernel16bit_hip, input, input_stride, pred, pred_stride, residual, residual_stride, area_width, area_height)
 
 // svt_aom_estimate_transform (Codec/transforms.c:3158-3225) without the pcs / ctx arguments (they only select the lossless WHT):
 // int16 residual -> packed coefficients (min(W,32) x min(H,32)) + the energy of the discarded frequencies, through the fused
 // RD kernel (a uint16 plane holding the residual's bit pattern against an all-zero prediction reproduces the residual exactly)
 int svt_hip_estimate_transform(int16_t *residual, uint32_t residual_stride, int32_t *coeff, int tx_size, uint64_t *three_quad_energy, int tx_type, int pf_shape) {
     if (tx_size < 0 || tx_size >= SVT_HIP_TX_SIZES_ALL || tx_type < 0 || tx_type >= SVT_HIP_TX_TYPES || pf_shape < 0 || pf_shape > 3 || !residual || !coeff) return SVT_HIP_ERR_BAD_PARAM;
+    try {
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
@@ -1163,13 +1245,14 @@ int svt_hip_estimate_transform(int16_t *residual, uint32_t residual_stride, int3
     d.src = d_src; d.pred = d_zero; d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.quant_rows = reinterpret_cast<const SvtHipQuantRow *>(d_row); d.n_quant_rows = 1;
     d.eob = reinterpret_cast<uint16_t *>(d_out); d.satd = reinterpret_cast<uint32_t *>(d_out + 8); d.dist_coeff = reinterpret_cast<uint64_t *>(d_out + 16);
     d.three_quad_energy = reinterpret_cast<uint64_t *>(d_out + 32); d.sse = reinterpret_cast<uint64_t *>(d_out + 40); d.coeff = reinterpret_cast<int32_t *>(d_coeff);
-    if (svt_hip_rd_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
+    if (svt_hip_rd_batch(ctx, &d) != SVT_HIP_OK) leaf_fail("%s", svt_hip_err_buf());
     leaf_check(ctx, hipMemcpyAsync(coeff, d_coeff, (size_t)NP * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     uint64_t tq = 0;
     leaf_check(ctx, hipMemcpyAsync(&tq, d_out + 32, 8, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     if (three_quad_energy) *three_quad_energy = tq;
     return SVT_HIP_OK;
+    } catch (const LeafFailure &f) { return svt_hip_fail(nullptr, SVT_HIP_ERR_LAUNCH, "svt_hip_estimate_transform: %s", f.what); }
 }
 
 } // extern "C"
@@ -1302,29 +1385,29 @@ extern "C" {
 
 void svt_ext_all_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t mv, uint32_t *p_best_sad_8x8,
                                                uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t p_eight_sad16x16[16][8],
-                                               uint32_t p_eight_sad8x8[64][8], bool sub_sad) {
+                                               uint32_t p_eight_sad8x8[64][8], bool sub_sad) LEAF_TRY
     (void)p_eight_sad8x8; // left untouched, like the C body (motion_estimation.c:335-362 never stores to it)
     leaf_ext_8x8_16x16(src, src_stride, ref, ref_stride, mv, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, &p_eight_sad16x16[0][0], nullptr,
                        sub_sad, 16, 8);
-}
+LEAF_CATCH(svt_ext_all_sad_calculation_8x8_16x16_hip, src, src_stride, ref, ref_stride, mv, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, p_eight_sad16x16, p_eight_sad8x8, sub_sad)
 
 void svt_ext_sad_calculation_8x8_16x16_hip(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride, uint32_t *p_best_sad_8x8,
                                            uint32_t *p_best_sad_16x16, uint32_t *p_best_mv8x8, uint32_t *p_best_mv16x16, uint32_t mv, uint32_t *p_sad16x16,
-                                           uint32_t *p_sad8x8, bool sub_sad) {
+                                           uint32_t *p_sad8x8, bool sub_sad) LEAF_TRY
     leaf_ext_8x8_16x16(src, src_stride, ref, ref_stride, mv, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, p_sad16x16, p_sad8x8, sub_sad, 1, 1);
-}
+LEAF_CATCH(svt_ext_sad_calculation_8x8_16x16_hip, src, src_stride, ref, ref_stride, p_best_sad_8x8, p_best_sad_16x16, p_best_mv8x8, p_best_mv16x16, mv, p_sad16x16, p_sad8x8, sub_sad)
 
 void svt_ext_eight_sad_calculation_32x32_64x64_hip(uint32_t p_sad16x16[16][8], uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
-                                                   uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]) {
+                                                   uint32_t *p_best_mv64x64, uint32_t mv, uint32_t p_sad32x32[4][8]) LEAF_TRY
     leaf_ext_32x32_64x64(&p_sad16x16[0][0], 8, mv, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, &p_sad32x32[0][0]);
-}
+LEAF_CATCH(svt_ext_eight_sad_calculation_32x32_64x64_hip, p_sad16x16, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, mv, p_sad32x32)
 
 void svt_ext_sad_calculation_32x32_64x64_hip(uint32_t *p_sad16x16, uint32_t *p_best_sad_32x32, uint32_t *p_best_sad_64x64, uint32_t *p_best_mv32x32,
-                                             uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32) {
+                                             uint32_t *p_best_mv64x64, uint32_t mv, uint32_t *p_sad32x32) LEAF_TRY
     leaf_ext_32x32_64x64(p_sad16x16, 1, mv, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, p_sad32x32);
-}
+LEAF_CATCH(svt_ext_sad_calculation_32x32_64x64_hip, p_sad16x16, p_best_sad_32x32, p_best_sad_64x64, p_best_mv32x32, p_best_mv64x64, mv, p_sad32x32)
 
-void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) {
+void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint32_t count32, uint32_t value) LEAF_TRY
     const uint32_t n = count128 * 4 + count32; // me_sad_calculation.c:14-17
     if (!n) return;
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
@@ -1335,7 +1418,7 @@ void svt_initialize_buffer_32bits_hip(uint32_t *pointer, uint32_t count128, uint
     leaf_check(ctx, hipGetLastError(), "fill_u32_kernel launch");
     leaf_check(ctx, hipMemcpyAsync(pointer, d, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-}
+LEAF_CATCH(svt_initialize_buffer_32bits_hip, pointer, count128, count32, value)
 
 } // extern "C"
 
@@ -1440,11 +1523,11 @@ extern "C" {
 #define SVT_HIP_QUANT_B(NAME, HBD)                                                                                                                        \
     void NAME(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,                 \
               const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, \
-              const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, const int32_t log_scale) {                                            \
+              const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, const int32_t log_scale) LEAF_TRY                                     \
         (void)scan;                                                                                                                                      \
         leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, qm_ptr, iqm_ptr, \
                       log_scale, HBD, 0);                                                                                                                \
-    }
+    LEAF_CATCH(NAME, coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, scan, iscan, qm_ptr, iqm_ptr, log_scale)
 SVT_HIP_QUANT_B(svt_aom_quantize_b_hip, 0)
 SVT_HIP_QUANT_B(svt_aom_highbd_quantize_b_hip, 1)
 SVT_HIP_QUANT_B(svt_av1_quantize_b_qm_hip, 0)
@@ -1454,11 +1537,11 @@ SVT_HIP_QUANT_B(svt_av1_highbd_quantize_b_qm_hip, 1)
 #define SVT_HIP_QUANT_FP(NAME, LS)                                                                                                                       \
     void NAME(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,                 \
               const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, \
-              const int16_t *iscan) {                                                                                                                    \
+              const int16_t *iscan) LEAF_TRY                                                                                                             \
         (void)scan;                                                                                                                                      \
         leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, nullptr, nullptr, \
                       LS, 0, 1);                                                                                                                         \
-    }
+    LEAF_CATCH(NAME, coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, scan, iscan)
 SVT_HIP_QUANT_FP(svt_av1_quantize_fp_hip, 0)
 SVT_HIP_QUANT_FP(svt_av1_quantize_fp_32x32_hip, 1)
 SVT_HIP_QUANT_FP(svt_av1_quantize_fp_64x64_hip, 2)
@@ -1466,22 +1549,22 @@ SVT_HIP_QUANT_FP(svt_av1_quantize_fp_64x64_hip, 2)
 
 void svt_av1_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
                                 const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
-                                const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale) {
+                                const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale) LEAF_TRY
     (void)scan;
     leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, qm_ptr, iqm_ptr, log_scale, 0, 1);
-}
+LEAF_CATCH(svt_av1_quantize_fp_qm_hip, coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, scan, iscan, qm_ptr, iqm_ptr, log_scale)
 void svt_av1_highbd_quantize_fp_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
                                     const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
-                                    const int16_t *scan, const int16_t *iscan, int16_t log_scale) {
+                                    const int16_t *scan, const int16_t *iscan, int16_t log_scale) LEAF_TRY
     (void)scan;
     leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, nullptr, nullptr, log_scale, 1, 1);
-}
+LEAF_CATCH(svt_av1_highbd_quantize_fp_hip, coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, scan, iscan, log_scale)
 void svt_av1_highbd_quantize_fp_qm_hip(const int32_t *coeff_ptr, intptr_t n_coeffs, const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr,
                                        const int16_t *quant_shift_ptr, int32_t *qcoeff_ptr, int32_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
-                                       const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale) {
+                                       const int16_t *scan, const int16_t *iscan, const uint8_t *qm_ptr, const uint8_t *iqm_ptr, int16_t log_scale) LEAF_TRY
     (void)scan;
     leaf_quantize(coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, qm_ptr, iqm_ptr, log_scale, 1, 1);
-}
+LEAF_CATCH(svt_av1_highbd_quantize_fp_qm_hip, coeff_ptr, n_coeffs, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr, qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, scan, iscan, qm_ptr, iqm_ptr, log_scale)
 
 } // extern "C"
 
@@ -1495,8 +1578,7 @@ void leaf_inv_txfm(const int32_t *input, const uint16_t *out_r, int32_t stride_r
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
     if ((bd != 8 && bd != 10) || tx_size < 0 || tx_size >= SVT_HIP_TX_SIZES_ALL || tx_type < 0 || tx_type >= SVT_HIP_TX_TYPES || stride_r <= 0 || stride_w <= 0) {
-        fprintf(stderr, "libsvthip: svt_av1_inv_txfm2d_add_hip: unsupported bd %d / tx_size %d / tx_type %d\n", bd, tx_size, tx_type);
-        abort();
+        leaf_fail("svt_av1_inv_txfm2d_add_hip: unsupported bd %d / tx_size %d / tx_type %d", bd, tx_size, tx_type);
     }
     const int W = svt_hip_tx_size_wide(tx_size), H = svt_hip_tx_size_high(tx_size), NP = (W > 32 ? 32 : W) * (H > 32 ? 32 : H);
     const size_t cb = align256((size_t)NP * 4), rbytes = (((size_t)H - 1) * stride_r + W) * 2, wbytes = (size_t)W * H * 2;
@@ -1512,7 +1594,7 @@ void leaf_inv_txfm(const int32_t *input, const uint16_t *out_r, int32_t stride_r
     memset(&d, 0, sizeof(d));
     d.bit_depth = (uint8_t)bd; d.sample_bytes = 2; d.tx_size = (uint8_t)tx_size; d.n_jobs = 1; d.pred_stride = (uint32_t)stride_r; d.recon_stride = (uint32_t)W;
     d.pred = d_pred; d.recon = d_rec; d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.dqcoeff = reinterpret_cast<const int32_t *>(d_co);
-    if (svt_hip_inv_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
+    if (svt_hip_inv_txfm_batch(ctx, &d) != SVT_HIP_OK) leaf_fail("%s", svt_hip_err_buf());
     leaf_check(ctx, hipMemcpy2DAsync(out_w, (size_t)stride_w * 2, d_rec, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpy2DAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -1522,26 +1604,25 @@ extern "C" {
 // TxType and TxSize are one-byte (ATTRIBUTE_PACKED) enums in the reference (definitions.h): uint8_t is the same ABI
 #define SVT_HIP_INV_SQ(W, H, TS)                                                                                                                       \
     void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, \
-                                                int32_t bd) {                                                                                         \
+                                                int32_t bd) LEAF_TRY                                                                                  \
         leaf_inv_txfm(input, output_r, stride_r, output_w, stride_w, tx_type, TS, bd);                                                                \
-    }
+    LEAF_CATCH(svt_av1_inv_txfm2d_add_##W##x##H##_hip, input, output_r, stride_r, output_w, stride_w, tx_type, bd)
 SVT_HIP_INV_SQ(4, 4, 0) SVT_HIP_INV_SQ(8, 8, 1) SVT_HIP_INV_SQ(16, 16, 2) SVT_HIP_INV_SQ(32, 32, 3) SVT_HIP_INV_SQ(64, 64, 4)
 #undef SVT_HIP_INV_SQ
 #define SVT_HIP_INV_RECT(W, H, TS)                                                                                                                     \
     void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, \
-                                                uint8_t tx_size, int32_t eob, int32_t bd) {                                                           \
-        (void)tx_size; (void)eob; /* eob only lets the reference skip zero rows; the result does not depend on it */                                  \
+                                                uint8_t tx_size, int32_t eob, int32_t bd) LEAF_TRY                                                    \
+        /* eob only lets the reference skip zero rows; the result does not depend on it */                                                            \
         leaf_inv_txfm(input, output_r, stride_r, output_w, stride_w, tx_type, TS, bd);                                                                \
-    }
+    LEAF_CATCH(svt_av1_inv_txfm2d_add_##W##x##H##_hip, input, output_r, stride_r, output_w, stride_w, tx_type, tx_size, eob, bd)
 SVT_HIP_INV_RECT(8, 16, 7) SVT_HIP_INV_RECT(16, 8, 8) SVT_HIP_INV_RECT(16, 32, 9) SVT_HIP_INV_RECT(32, 16, 10) SVT_HIP_INV_RECT(32, 64, 11) SVT_HIP_INV_RECT(64, 32, 12)
 SVT_HIP_INV_RECT(8, 32, 15) SVT_HIP_INV_RECT(32, 8, 16) SVT_HIP_INV_RECT(16, 64, 17) SVT_HIP_INV_RECT(64, 16, 18)
 #undef SVT_HIP_INV_RECT
 #define SVT_HIP_INV_SMALL(W, H, TS)                                                                                                                    \
     void svt_av1_inv_txfm2d_add_##W##x##H##_hip(const int32_t *input, uint16_t *output_r, int32_t stride_r, uint16_t *output_w, int32_t stride_w, uint8_t tx_type, \
-                                                uint8_t tx_size, int32_t bd) {                                                                        \
-        (void)tx_size;                                                                                                                                \
+                                                uint8_t tx_size, int32_t bd) LEAF_TRY                                                                 \
         leaf_inv_txfm(input, output_r, stride_r, output_w, stride_w, tx_type, TS, bd);                                                                \
-    }
+    LEAF_CATCH(svt_av1_inv_txfm2d_add_##W##x##H##_hip, input, output_r, stride_r, output_w, stride_w, tx_type, tx_size, bd)
 SVT_HIP_INV_SMALL(4, 8, 5) SVT_HIP_INV_SMALL(8, 4, 6) SVT_HIP_INV_SMALL(4, 16, 13) SVT_HIP_INV_SMALL(16, 4, 14)
 #undef SVT_HIP_INV_SMALL
 } // extern "C"
@@ -1555,7 +1636,7 @@ void leaf_fwd_txfm(const int16_t *input, int32_t *output, uint32_t stride, int t
     std::lock_guard<std::mutex> lock(g_leaf_mutex);
     SvtHipContext *ctx = leaf_ctx();
     hipSetDevice(ctx->device);
-    if (tx_type < 0 || tx_type >= SVT_HIP_TX_TYPES) { fprintf(stderr, "libsvthip: svt_av1_fwd_txfm2d_hip: tx_type %d\n", tx_type); abort(); }
+    if (tx_type < 0 || tx_type >= SVT_HIP_TX_TYPES) leaf_fail("svt_av1_fwd_txfm2d_hip: tx_type %d", tx_type);
     const int W = svt_hip_tx_size_wide(tx_size), H = svt_hip_tx_size_high(tx_size);
     const size_t rbytes = (((size_t)H - 1) * stride + W) * 2, obytes = (size_t)W * H * 4;
     uint8_t *base = leaf_scratch(ctx, align256(rbytes) + align256(obytes) + 256);
@@ -1569,7 +1650,7 @@ void leaf_fwd_txfm(const int16_t *input, int32_t *output, uint32_t stride, int t
     memset(&d, 0, sizeof(d));
     d.tx_size = (uint8_t)tx_size; d.n_jobs = 1; d.residual_stride = stride; d.residual = reinterpret_cast<const int16_t *>(d_res);
     d.jobs = reinterpret_cast<const SvtHipTxJob *>(d_job); d.coeff = reinterpret_cast<int32_t *>(d_out);
-    if (svt_hip_fwd_txfm_batch(ctx, &d) != SVT_HIP_OK) { fprintf(stderr, "libsvthip: %s\n", svt_hip_err_buf()); abort(); }
+    if (svt_hip_fwd_txfm_batch(ctx, &d) != SVT_HIP_OK) leaf_fail("%s", svt_hip_err_buf());
     leaf_check(ctx, hipMemcpyAsync(output, d_out, obytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     leaf_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -1577,15 +1658,15 @@ void leaf_fwd_txfm(const int16_t *input, int32_t *output, uint32_t stride, int t
 
 extern "C" {
 #define SVT_HIP_FWD(W, H, TS)                                                                                                                   \
-    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                   \
-        (void)bd; leaf_fwd_txfm(input, output, stride, tx_type, TS, 0);                                                                         \
-    }                                                                                                                                           \
-    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                \
-        (void)bd; leaf_fwd_txfm(input, output, stride, tx_type, TS, 1);                                                                         \
-    }                                                                                                                                           \
-    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) {                \
-        (void)bd; leaf_fwd_txfm(input, output, stride, tx_type, TS, 2);                                                                         \
-    }
+    void svt_av1_fwd_txfm2d_##W##x##H##_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) LEAF_TRY                   \
+        leaf_fwd_txfm(input, output, stride, tx_type, TS, 0);                                                                         \
+    LEAF_CATCH(svt_av1_fwd_txfm2d_##W##x##H##_hip, input, output, stride, tx_type, bd)                                                                                                                                           \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N2_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) LEAF_TRY                \
+        leaf_fwd_txfm(input, output, stride, tx_type, TS, 1);                                                                         \
+    LEAF_CATCH(svt_av1_fwd_txfm2d_##W##x##H##_N2_hip, input, output, stride, tx_type, bd)                                                                                                                                           \
+    void svt_av1_fwd_txfm2d_##W##x##H##_N4_hip(int16_t *input, int32_t *output, uint32_t stride, uint8_t tx_type, uint8_t bd) LEAF_TRY                \
+        leaf_fwd_txfm(input, output, stride, tx_type, TS, 2);                                                                         \
+    LEAF_CATCH(svt_av1_fwd_txfm2d_##W##x##H##_N4_hip, input, output, stride, tx_type, bd)
 SVT_HIP_FWD(4, 4, 0) SVT_HIP_FWD(8, 8, 1) SVT_HIP_FWD(16, 16, 2) SVT_HIP_FWD(32, 32, 3) SVT_HIP_FWD(64, 64, 4) SVT_HIP_FWD(4, 8, 5) SVT_HIP_FWD(8, 4, 6)
 SVT_HIP_FWD(8, 16, 7) SVT_HIP_FWD(16, 8, 8) SVT_HIP_FWD(16, 32, 9) SVT_HIP_FWD(32, 16, 10) SVT_HIP_FWD(32, 64, 11) SVT_HIP_FWD(64, 32, 12) SVT_HIP_FWD(4, 16, 13)
 SVT_HIP_FWD(16, 4, 14) SVT_HIP_FWD(8, 32, 15) SVT_HIP_FWD(32, 8, 16) SVT_HIP_FWD(16, 64, 17) SVT_HIP_FWD(64, 16, 18)
@@ -1634,14 +1715,14 @@ uint64_t leaf_handle_transform(int32_t *output, int w, int h, int with_energy) {
 } // namespace
 
 extern "C" {
-uint64_t svt_handle_transform16x64_hip(int32_t *output) { return leaf_handle_transform(output, 16, 64, 1); }
-uint64_t svt_handle_transform32x64_hip(int32_t *output) { return leaf_handle_transform(output, 32, 64, 1); }
-uint64_t svt_handle_transform64x16_hip(int32_t *output) { return leaf_handle_transform(output, 64, 16, 1); }
-uint64_t svt_handle_transform64x32_hip(int32_t *output) { return leaf_handle_transform(output, 64, 32, 1); }
-uint64_t svt_handle_transform64x64_hip(int32_t *output) { return leaf_handle_transform(output, 64, 64, 1); }
-uint64_t svt_handle_transform16x64_N2_N4_hip(int32_t *output) { (void)output; return 0; } // the reference's bodies are empty too (transforms.c:2514-2521)
-uint64_t svt_handle_transform32x64_N2_N4_hip(int32_t *output) { (void)output; return 0; }
-uint64_t svt_handle_transform64x16_N2_N4_hip(int32_t *output) { return leaf_handle_transform(output, 64, 16, 0); }
-uint64_t svt_handle_transform64x32_N2_N4_hip(int32_t *output) { return leaf_handle_transform(output, 64, 32, 0); }
-uint64_t svt_handle_transform64x64_N2_N4_hip(int32_t *output) { return leaf_handle_transform(output, 64, 64, 0); }
+uint64_t svt_handle_transform16x64_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 16, 64, 1); LEAF_CATCH(svt_handle_transform16x64_hip, output)
+uint64_t svt_handle_transform32x64_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 32, 64, 1); LEAF_CATCH(svt_handle_transform32x64_hip, output)
+uint64_t svt_handle_transform64x16_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 64, 16, 1); LEAF_CATCH(svt_handle_transform64x16_hip, output)
+uint64_t svt_handle_transform64x32_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 64, 32, 1); LEAF_CATCH(svt_handle_transform64x32_hip, output)
+uint64_t svt_handle_transform64x64_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 64, 64, 1); LEAF_CATCH(svt_handle_transform64x64_hip, output)
+uint64_t svt_handle_transform16x64_N2_N4_hip(int32_t *output) LEAF_TRY (void)output; return 0; LEAF_CATCH(svt_handle_transform16x64_N2_N4_hip, output) // the reference's bodies are empty too (transforms.c:2514-2521)
+uint64_t svt_handle_transform32x64_N2_N4_hip(int32_t *output) LEAF_TRY (void)output; return 0; LEAF_CATCH(svt_handle_transform32x64_N2_N4_hip, output)
+uint64_t svt_handle_transform64x16_N2_N4_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 64, 16, 0); LEAF_CATCH(svt_handle_transform64x16_N2_N4_hip, output)
+uint64_t svt_handle_transform64x32_N2_N4_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 64, 32, 0); LEAF_CATCH(svt_handle_transform64x32_N2_N4_hip, output)
+uint64_t svt_handle_transform64x64_N2_N4_hip(int32_t *output) LEAF_TRY return leaf_handle_transform(output, 64, 64, 0); LEAF_CATCH(svt_handle_transform64x64_N2_N4_hip, output)
 } // extern "C"

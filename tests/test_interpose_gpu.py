@@ -47,3 +47,38 @@ def test_reference_driver_runs_on_installed_hip_leaves(hip_ctx, ref, name):
         ref.ref_set_simd(0)  # back to the reference's `_c` kernels for every other test
         L.svt_hip_leaf_bind(None)
     assert not compare(case.expected, got, names=list(case.expected)), name
+
+
+def test_device_failure_falls_back_to_the_encoders_kernels(hip_ctx, ref):
+    """Fail closed on a live installation (csrc/leaf_guard.h): with the reference's `_c` kernels in the slots first, the installed `_hip`
+    entries run on the GPU; when the device fails (svt_hip_leaf_inject_failure) the same calls are served by the reference's own kernels --
+    the driver still produces the fixture's results, nothing aborts -- and the library says how many calls took that way."""
+    L = api.lib()
+    ref.ref_rtcd_slot.restype = C.c_void_p
+    slots = (RtcdSlot * len(SAD_POINTERS))()
+    ref.ref_set_simd(0)  # the reference's `_c` kernels are what the installer finds in the slots
+    for s, n in zip(slots, SAD_POINTERS):
+        s.name, s.slot = n.encode(), ref.ref_rtcd_slot(n.encode())
+    before = [C.c_void_p.from_address(s.slot).value for s in slots]
+    case = GoldenMeCase("me_cif_m12_b")
+    fb, un = C.c_ulonglong(0), C.c_ulonglong(0)
+    try:
+        assert L.svt_hip_install_rtcd(hip_ctx._h, slots, len(slots), None) == 0
+        ref.ref_set_simd(2)
+        L.svt_hip_leaf_status(None, None, None, C.c_size_t(0))
+        got_gpu = pyoracle.me_picture("ref", case.cfg, case.desc, case.cur, case.refs)
+        assert L.svt_hip_leaf_status(C.byref(fb), C.byref(un), None, C.c_size_t(0)) == 0  # every call ran on the device
+        L.svt_hip_leaf_inject_failure(1)
+        got_fallback = pyoracle.me_picture("ref", case.cfg, case.desc, case.cur, case.refs)
+        L.svt_hip_leaf_inject_failure(0)
+        assert L.svt_hip_leaf_status(C.byref(fb), C.byref(un), None, C.c_size_t(0)) > 0 and fb.value > 0 and un.value == 0
+        got_again = pyoracle.me_picture("ref", case.cfg, case.desc, case.cur, case.refs)
+        assert L.svt_hip_leaf_status(C.byref(fb), C.byref(un), None, C.c_size_t(0)) == 0
+    finally:
+        L.svt_hip_leaf_inject_failure(0)
+        L.svt_hip_uninstall_rtcd(slots, len(slots))
+        ref.ref_set_simd(0)
+        L.svt_hip_leaf_bind(None)
+    assert [C.c_void_p.from_address(s.slot).value for s in slots] == before  # uninstall put the reference's kernels back
+    for got in (got_gpu, got_fallback, got_again):
+        assert not compare(case.expected, got, names=list(case.expected))
