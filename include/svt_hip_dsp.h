@@ -51,7 +51,8 @@ typedef struct SvtHipTxJob {
 
 typedef struct SvtHipRdBatchDesc {
     uint8_t  bit_depth;     /* 8: planes are uint8; 10: planes are uint16 */
-    uint8_t  quant_kind;    /* 0 = "b" (zbin / quant_shift), 1 = "fp" */
+    uint8_t  quant_kind;    /* 0 = "b" (zbin / quant_shift), 1 = "fp", 2 = "fp" with the log-scale of the size forced to 0: the TPL
+                             * dispenser calls plain svt_av1_quantize_fp for every transform size (get_quantize_error, Codec/src_ops_process.c:225-249) */
     uint8_t  tx_size;       /* TxSize shared by every job of this call (one kernel instantiation per size) */
     uint8_t  reserved;
     uint32_t n_jobs;

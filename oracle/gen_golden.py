@@ -235,23 +235,24 @@ def gen_dg_detector():
 
 
 def gen_tpl_chain():
-    """The reference's TPL kernel chain (ref_harness.c:ref_tpl_chain) on tests/tpl_cases.py's grid: per job {inter_cost, eob, recon_error, sse}."""
-    from tpl_cases import GRID, W, batch, planes
+    """The reference's TPL kernel chain (ref_harness.c:ref_tpl_chain) on tests/tpl_cases.py's grid (dispenser levels 0 and 1: 16x16 and
+    32x32 blocks, each with its row-sub-sampled transforms): per job {inter_cost, eob, recon_error, sse}."""
+    from tpl_cases import GRID, W, batch, planes, seed_of
     ref = pyoracle.load_ref()
-    res = []
-    for sub, pf, amp in GRID:
-        src, pred = planes(100 + sub * 10 + pf, amp)
-        _, jobs, rows = batch(sub, pf)
-        co, q, dq = (np.zeros(256, np.int32) for _ in range(3))
+    res = {}
+    for i, (level, sub, pf, amp) in enumerate(GRID):
+        src, pred = planes(seed_of(level, sub, pf), amp)
+        _, jobs, rows = batch(level, sub, pf)
+        co, q, dq = (np.zeros(1024, np.int32) for _ in range(3))
         per = np.zeros((len(jobs), 4), np.int64)
         for j, jb in enumerate(jobs):
             off = int(jb["src_offset"])
-            assert ref.ref_tpl_chain(C.c_void_p(src.ctypes.data + off), W, C.c_void_p(pred.ctypes.data + off), W, sub, pf,
+            assert ref.ref_tpl_chain(C.c_void_p(src.ctypes.data + off), W, C.c_void_p(pred.ctypes.data + off), W, level, sub, pf,
                                      C.c_void_p(rows.ctypes.data + int(jb["quant_row"]) * rows.dtype.itemsize), co.ctypes.data_as(C.c_void_p),
                                      q.ctypes.data_as(C.c_void_p), dq.ctypes.data_as(C.c_void_p), per[j].ctypes.data_as(C.c_void_p)) == 0
-        res.append(per)
-    np.savez_compressed(os.path.join(OUT, "tpl_chain.npz"), grid=np.array(GRID), results=np.stack(res))
-    print("tpl_chain.npz", np.stack(res).shape)
+        res[f"results_{i}"] = per
+    np.savez_compressed(os.path.join(OUT, "tpl_chain.npz"), grid=np.array(GRID), **res)
+    print("tpl_chain.npz", len(res), "configurations")
 
 
 def gen_rd_chain():

@@ -62,7 +62,8 @@ int orc_rd_batch(const SvtHipRdBatchDesc *d) {
         if (d->quant_kind == 0)
             orc_quantize_b(co, NP, qr->zbin, qr->round, qr->quant, qr->quant_shift, q, dq, qr->dequant, &d->eob[j], scan[kind], qm, iqm, k_log_scale[ts], hbd);
         else
-            orc_quantize_fp(co, NP, qr->round_fp, qr->quant_fp, q, dq, qr->dequant, &d->eob[j], scan[kind], qm, iqm, k_log_scale[ts], hbd);
+            orc_quantize_fp(co, NP, qr->round_fp, qr->quant_fp, q, dq, qr->dequant, &d->eob[j], scan[kind], qm, iqm,
+                            d->quant_kind == 2 ? 0 : k_log_scale[ts] /* 2: the TPL dispenser's plain svt_av1_quantize_fp, src_ops_process.c:225-249 */, hbd);
         if (d->cul_level) d->cul_level[j] = orc_compute_cul_level(scan[kind], q, &d->eob[j]); /* full_loop.c:1832-1836 */
         orc_full_distortion32(co, WP, dq, WP, &d->dist_coeff[2 * (size_t)j], WP, HP);
         for (int r = 0; r < H; r++)

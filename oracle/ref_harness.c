@@ -574,11 +574,14 @@ int ref_rd_batch(const SvtHipRdBatchDesc *d) {
  * ===================================================================================================================== */
 void svt_av1_wht_fwd_txfm(int16_t *src_diff, int bw, int32_t *coeff, TxSize tx_size, EB_TRANS_COEFF_SHAPE pf_shape, int bit_depth, int is_hbd);
 
-int ref_tpl_chain(const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride, int sub, int pf_shape,
+int ref_tpl_chain(const uint8_t *src, uint32_t src_stride, const uint8_t *pred, uint32_t pred_stride, int level, int sub, int pf_shape,
                   const SvtHipQuantRow *qr, int32_t *coeff, int32_t *qcoeff, int32_t *dqcoeff, int64_t *out4) {
-    static const TxSize sizes[3] = {TX_16X16, TX_16X8, TX_16X4};
-    const TxSize tx_size = sizes[sub];
-    const int    size    = 16;
+    /* tx_size_array / sub2_tx_size_array / sub4_tx_size_array of dispenser levels 0 and 1 (src_ops_process.c:377-382; level 2 is never
+     * selected -- initial_rc_process.c:308-368 -- and its 64x64 transform would not fit the dispenser's MAX_TPL_SIZE = 32 buffers) */
+    static const TxSize sizes[2][3] = {{TX_16X16, TX_16X8, TX_16X4}, {TX_32X32, TX_32X16, TX_32X8}};
+    if (level < 0 || level > 1 || sub < 0 || sub > 2) return 1;
+    const TxSize tx_size = sizes[level][sub];
+    const int    size    = 16 << level;
     svt_aom_subtract_block = svt_aom_subtract_block_c;
     svt_aom_satd           = svt_aom_satd_c;
     svt_av1_quantize_fp    = svt_av1_quantize_fp_c;
@@ -586,7 +589,10 @@ int ref_tpl_chain(const uint8_t *src, uint32_t src_stride, const uint8_t *pred, 
     svt_av1_fwd_txfm2d_16x16 = svt_av1_transform_two_d_16x16_c; svt_av1_fwd_txfm2d_16x8 = svt_av1_fwd_txfm2d_16x8_c; svt_av1_fwd_txfm2d_16x4 = svt_av1_fwd_txfm2d_16x4_c;
     svt_av1_fwd_txfm2d_16x16_N2 = svt_aom_transform_two_d_16x16_N2_c; svt_av1_fwd_txfm2d_16x8_N2 = svt_av1_fwd_txfm2d_16x8_N2_c; svt_av1_fwd_txfm2d_16x4_N2 = svt_av1_fwd_txfm2d_16x4_N2_c;
     svt_av1_fwd_txfm2d_16x16_N4 = svt_aom_transform_two_d_16x16_N4_c; svt_av1_fwd_txfm2d_16x8_N4 = svt_av1_fwd_txfm2d_16x8_N4_c; svt_av1_fwd_txfm2d_16x4_N4 = svt_av1_fwd_txfm2d_16x4_N4_c;
-    DECLARE_ALIGNED(16, int16_t, src_diff[16 * 16]);
+    svt_av1_fwd_txfm2d_32x32 = svt_av1_transform_two_d_32x32_c; svt_av1_fwd_txfm2d_32x16 = svt_av1_fwd_txfm2d_32x16_c; svt_av1_fwd_txfm2d_32x8 = svt_av1_fwd_txfm2d_32x8_c;
+    svt_av1_fwd_txfm2d_32x32_N2 = svt_aom_transform_two_d_32x32_N2_c; svt_av1_fwd_txfm2d_32x16_N2 = svt_av1_fwd_txfm2d_32x16_N2_c; svt_av1_fwd_txfm2d_32x8_N2 = svt_av1_fwd_txfm2d_32x8_N2_c;
+    svt_av1_fwd_txfm2d_32x32_N4 = svt_aom_transform_two_d_32x32_N4_c; svt_av1_fwd_txfm2d_32x16_N4 = svt_av1_fwd_txfm2d_32x16_N4_c; svt_av1_fwd_txfm2d_32x8_N4 = svt_av1_fwd_txfm2d_32x8_N4_c;
+    DECLARE_ALIGNED(16, int16_t, src_diff[32 * 32]);
     DECLARE_ALIGNED(16, int16_t, zbin[8]); DECLARE_ALIGNED(16, int16_t, rnd[8]); DECLARE_ALIGNED(16, int16_t, qnt[8]);
     DECLARE_ALIGNED(16, int16_t, qsh[8]); DECLARE_ALIGNED(16, int16_t, deq[8]);
     for (int k = 0; k < 8; k++) { zbin[k] = qr->zbin[k != 0]; rnd[k] = qr->round_fp[k != 0]; qnt[k] = qr->quant_fp[k != 0]; qsh[k] = qr->quant_shift[k != 0]; deq[k] = qr->dequant[k != 0]; }

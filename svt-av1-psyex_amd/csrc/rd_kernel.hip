@@ -505,7 +505,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     // reads what an earlier one overwrote (its reads start beyond the earlier iteration's writes), and within one
     // iteration the wave's loads precede its stores.
     const SvtHipQuantRow q = p.d.quant_rows[jb.quant_row];
-    const int     log_scale = c_log_scale[TS];
+    const int     log_scale = p.d.quant_kind == 2 ? 0 : c_log_scale[TS]; // quant_kind 2: the TPL dispenser's plain svt_av1_quantize_fp call (src_ops_process.c:225-249)
     const int16_t *iscan    = p.iscan[(tt >= 10) ? ((tt & 1) ? 2 : 1) : 0];
     const uint8_t *qm = (tt < 9) ? p.d.qmatrix : nullptr, *iqm = (tt < 9) ? p.d.iqmatrix : nullptr; // IS_2D_TRANSFORM, full_loop.c:1606-1608
     uint32_t satd = 0, eob = 0, qsum = 0; // qsum: sum of min(|qcoeff|, 63) = svt_av1_compute_cul_level's running sum up to its clamp
@@ -877,7 +877,7 @@ int svt_hip_scan_order(int tx_size, int tx_type, int16_t *scan, int16_t *iscan) 
 int svt_hip_rd_batch(SvtHipContext *ctx, const SvtHipRdBatchDesc *d) {
     if (!ctx || !d) return SVT_HIP_ERR_BAD_PARAM;
     if (d->n_jobs == 0) return SVT_HIP_OK;
-    if ((d->bit_depth != 8 && d->bit_depth != 10) || d->quant_kind > 1)
+    if ((d->bit_depth != 8 && d->bit_depth != 10) || d->quant_kind > 2)
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "bit_depth %u / quant_kind %u", d->bit_depth, d->quant_kind);
     if (!d->src || !d->pred || !d->jobs || !d->quant_rows || !d->eob || !d->satd || !d->dist_coeff || !d->three_quad_energy || !d->sse)
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the RD batch is null");
