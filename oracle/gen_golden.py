@@ -281,7 +281,32 @@ def gen_pyramid():
     np.savez_compressed(os.path.join(OUT, "pyramid.npz"), **out)
 
 
-GENERATORS = {"pyramid": gen_pyramid, "me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats, "dg": gen_dg_detector, "tpl": gen_tpl_chain, "rd": gen_rd_chain}
+def gen_md_search():
+    """The reference's md_full_pel_search chains and svt_av1_find_best_sub_pixel_tree_pruned (oracle/ref_harness_md.c) on tests/md_search_cases.py's grids."""
+    import md_search_cases as mc
+    ref = pyoracle.load_ref()
+    out = {}
+    for gi, (dist, psad, ctype) in enumerate(mc.FULLPEL_GRID):
+        rng = np.random.default_rng(100 + dist * 10 + psad * 3 + ctype)
+        src, refp = mc.planes(7 + dist)
+        tables = mc.cost_tables(rng)
+        rounds = mc.fullpel_chain(rng, 40, dist, psad)
+        got = mc.run_fullpel_cpu(ref.ref_md_fullpel_batch, src, refp, rounds, ctype, 37, tables)
+        out[f"fp_cost_{gi}"] = np.stack([c for c, _ in got])
+        out[f"fp_mv_{gi}"] = np.stack([m for _, m in got])
+    for si in range(len(mc.SUBPEL_SETTINGS)):
+        rng = np.random.default_rng(300 + si)
+        src, refp = mc.planes(11 + si)
+        tables = mc.cost_tables(rng)
+        jobs = mc.subpel_jobs(rng, 60)
+        got = mc.run_subpel_cpu(ref.ref_md_subpel_batch, src, refp, jobs, mc.SUBPEL_SETTINGS[si], 41, 36, tables)
+        for k, v in got.items():
+            out[f"sp_{k}_{si}"] = v
+    np.savez_compressed(os.path.join(OUT, "md_search.npz"), **out)
+    print("md_search.npz", len(out), "arrays")
+
+
+GENERATORS = {"md": gen_md_search, "pyramid": gen_pyramid, "me": gen_me, "me_mctf": lambda: gen_me(only=["me_vga_m4_mctf"]), "sad": gen_sad_kernels, "presets": gen_presets, "stats": gen_block_stats, "dg": gen_dg_detector, "tpl": gen_tpl_chain, "rd": gen_rd_chain}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

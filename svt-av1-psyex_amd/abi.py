@@ -210,3 +210,30 @@ class PmeBatchDesc(C.Structure):
     _fields_ = [("n_jobs", C.c_uint32), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("src", C.c_void_p), ("ref", C.c_void_p), ("jobs", C.c_void_p),
                 ("mv_cost_type", C.c_int32), ("error_per_bit", C.c_int32), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2), ("best_cost", C.c_void_p),
                 ("best_mv", C.c_void_p)]
+
+
+# ---- include/svt_hip_md_search.h ----
+FULLPEL_JOB_DTYPE = np.dtype([("src_offset", "<u4"), ("blk_org_x", "<i4"), ("blk_org_y", "<i4"), ("width", "u1"), ("height", "u1"), ("dist_type", "u1"), ("flags", "u1"),
+                              ("mvx", "<i2"), ("mvy", "<i2"), ("start_x", "<i2"), ("end_x", "<i2"), ("start_y", "<i2"), ("end_y", "<i2"), ("step", "<i2"),
+                              ("sprs_lev0_start_x", "<i2"), ("sprs_lev0_end_x", "<i2"), ("sprs_lev0_start_y", "<i2"), ("sprs_lev0_end_y", "<i2"), ("ref_mv", "<i2", (2,)),
+                              ("best_cost", "<u4"), ("best_mvx", "<i2"), ("best_mvy", "<i2"), ("chain_from", "<i4")], align=True)
+FP_CENTRE_FROM_CHAIN, FP_BEST_FROM_CHAIN, FP_SPRS_LEV0_DONE, FP_ENABLE_PSAD = 1, 2, 4, 8
+
+
+class FullpelBatchDesc(C.Structure):
+    _fields_ = [("n_jobs", C.c_uint32), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("src", C.c_void_p), ("ref", C.c_void_p), ("ref_org_x", C.c_int32),
+                ("ref_org_y", C.c_int32), ("ref_max_width", C.c_int32), ("ref_max_height", C.c_int32), ("jobs", C.c_void_p), ("mv_cost_type", C.c_int32),
+                ("error_per_bit", C.c_int32), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2), ("best_cost", C.c_void_p), ("best_mv", C.c_void_p)]
+
+
+SUBPEL_JOB_DTYPE = np.dtype([("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("log2_pels", "u1"), ("early_neigh_check_exit", "u1"),
+                             ("start_mv", "<i2", (2,)), ("ref_mv", "<i2", (2,)), ("col_min", "<i2"), ("col_max", "<i2"), ("row_min", "<i2"), ("row_max", "<i2"),
+                             ("early_exit_th", "<i4")], align=True)
+
+
+class SubpelBatchDesc(C.Structure):
+    _fields_ = [("n_jobs", C.c_uint32), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("src", C.c_void_p), ("ref", C.c_void_p), ("jobs", C.c_void_p),
+                ("allow_hp", C.c_int32), ("forced_stop", C.c_int32), ("iters_per_step", C.c_int32), ("pred_variance_th", C.c_int32), ("abs_th_mult", C.c_int32),
+                ("round_dev_th", C.c_int32), ("skip_diag_refinement", C.c_int32), ("bias_fp", C.c_int32), ("qp", C.c_int32), ("mv_cost_type", C.c_int32),
+                ("error_per_bit", C.c_int32), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2), ("best_mv", C.c_void_p), ("besterr", C.c_void_p),
+                ("distortion", C.c_void_p), ("sse", C.c_void_p)]

@@ -1,0 +1,68 @@
+"""CPU: the mode-decision side motion search (include/svt_hip_md_search.h).  The oracle's restatement (oracle/md_search_oracle.c) against the
+REFERENCE's own md_full_pel_search and svt_av1_find_best_sub_pixel_tree_pruned (oracle/ref_harness_md.c, build container), and against the
+committed outputs of the reference (tests/golden/md_search.npz) everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+import md_search_cases as mc
+import pyoracle
+from svt_av1_psyex_amd import abi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md_search.npz")
+
+
+def test_struct_sizes(oracle):
+    oracle.orc_sizeof_md_search.restype = __import__("ctypes").c_size_t
+    import ctypes as C
+    assert oracle.orc_sizeof_md_search(0) == abi.FULLPEL_JOB_DTYPE.itemsize and oracle.orc_sizeof_md_search(1) == C.sizeof(abi.FullpelBatchDesc)
+    assert oracle.orc_sizeof_md_search(2) == abi.SUBPEL_JOB_DTYPE.itemsize and oracle.orc_sizeof_md_search(3) == C.sizeof(abi.SubpelBatchDesc)
+
+
+@pytest.mark.parametrize("dist,psad,ctype", mc.FULLPEL_GRID)
+def test_fullpel_chain_oracle_equals_reference(oracle, ref, dist, psad, ctype):
+    rng = np.random.default_rng(100 + dist * 10 + psad * 3 + ctype)
+    src, refp = mc.planes(7 + dist)
+    tables = mc.cost_tables(rng)
+    rounds = mc.fullpel_chain(rng, 40, dist, psad)
+    a = mc.run_fullpel_cpu(ref.ref_md_fullpel_batch, src, refp, rounds, ctype, 37, tables)
+    b = mc.run_fullpel_cpu(oracle.orc_md_fullpel_batch, src, refp, rounds, ctype, 37, tables)
+    for r, ((ca, ma), (cb, mb)) in enumerate(zip(a, b)):
+        np.testing.assert_array_equal(ca, cb, err_msg=f"round {r} cost")
+        np.testing.assert_array_equal(ma, mb, err_msg=f"round {r} mv")
+    assert len({tuple(m) for m in a[-1][1]}) > 10  # the chains really moved
+
+
+@pytest.mark.parametrize("si", range(len(mc.SUBPEL_SETTINGS)))
+def test_subpel_tree_pruned_oracle_equals_reference(oracle, ref, si):
+    rng = np.random.default_rng(300 + si)
+    src, refp = mc.planes(11 + si)
+    tables = mc.cost_tables(rng)
+    jobs = mc.subpel_jobs(rng, 60)
+    a = mc.run_subpel_cpu(ref.ref_md_subpel_batch, src, refp, jobs, mc.SUBPEL_SETTINGS[si], 41, 36, tables)
+    b = mc.run_subpel_cpu(oracle.orc_md_subpel_batch, src, refp, jobs, mc.SUBPEL_SETTINGS[si], 41, 36, tables)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    if mc.SUBPEL_SETTINGS[si][1] < 3:
+        assert (a["best_mv"] % 8 != 0).any()  # some searches ended on a fractional position
+
+
+def test_oracle_vs_golden(oracle):
+    z = np.load(GOLDEN)
+    for gi, (dist, psad, ctype) in enumerate(mc.FULLPEL_GRID):
+        rng = np.random.default_rng(100 + dist * 10 + psad * 3 + ctype)
+        src, refp = mc.planes(7 + dist)
+        tables = mc.cost_tables(rng)
+        rounds = mc.fullpel_chain(rng, 40, dist, psad)
+        got = mc.run_fullpel_cpu(oracle.orc_md_fullpel_batch, src, refp, rounds, ctype, 37, tables)
+        np.testing.assert_array_equal(np.stack([c for c, _ in got]), z[f"fp_cost_{gi}"])
+        np.testing.assert_array_equal(np.stack([m for _, m in got]), z[f"fp_mv_{gi}"])
+    for si in range(len(mc.SUBPEL_SETTINGS)):
+        rng = np.random.default_rng(300 + si)
+        src, refp = mc.planes(11 + si)
+        tables = mc.cost_tables(rng)
+        jobs = mc.subpel_jobs(rng, 60)
+        got = mc.run_subpel_cpu(oracle.orc_md_subpel_batch, src, refp, jobs, mc.SUBPEL_SETTINGS[si], 41, 36, tables)
+        for k in got:
+            np.testing.assert_array_equal(got[k], z[f"sp_{k}_{si}"], err_msg=f"{k} {si}")
