@@ -516,6 +516,40 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     int32_t *dq_out = (p.d.dqcoeff && valid) ? p.d.dqcoeff + (size_t)job * NP : nullptr;
     const int32_t zb_c[2]  = {log_scale ? ((q.zbin[0] + (1 << (log_scale - 1))) >> log_scale) : q.zbin[0], log_scale ? ((q.zbin[1] + (1 << (log_scale - 1))) >> log_scale) : q.zbin[1]};
     const int32_t rnd_c[2] = {log_scale ? ((q.round[0] + (1 << (log_scale - 1))) >> log_scale) : q.round[0], log_scale ? ((q.round[1] + (1 << (log_scale - 1))) >> log_scale) : q.round[1]};
+    // The common case as a loop of its own (wave-uniform test): "b" quantizer, flat matrix, every coefficient of the wave below 2^16, the whole
+    // block kept, nothing but the quantized coefficients asked for.  A lane's first coefficient may be the DC one (its constants are
+    // selected per lane); all later ones are AC, whose constants stay in scalar registers.  Every product has 24-bit operands (see the
+    // general loop below), |coeff - dqcoeff| <= max(|coeff|, dequant) < 2^16: the squares are exact in 32 bits.
+    const bool fast_q = q24 && !qm && p.d.quant_kind == 0 && !co_out && !dq_out && __all(pf == 0); // (co_out / dq_out: null for every job or none)
+    if (fast_q) {
+        static_assert(NP % LW == 0, "every lane of a block walks the same number of coefficients");
+        auto one = [&](int rc, int32_t zb, int32_t rnd, int32_t quant, int32_t qshift, int32_t deq) {
+            const int r = rc / WP, c = rc - r * WP; // WP is a power of two
+            const int32_t co = A[r * PA + c], sign = co >> 31, a = (co ^ sign) - sign;
+            satd += (uint32_t)a;
+            int32_t t = a + rnd;
+            if (BD == 8) t = t > 32767 ? 32767 : t;
+            const int32_t tmp = mul24_shr(t, quant, 11) + (t << 5);
+            int32_t qv = mul24_shr(tmp, qshift, 21 - log_scale);
+            qv = a >= zb ? qv : 0;
+            const int32_t dq = __mul24(qv, deq) >> log_scale;
+            const int32_t qs = (qv ^ sign) - sign, dqs = (dq ^ sign) - sign;
+            const uint32_t e = qv ? (uint32_t)iscan[rc] + 1u : 0u;
+            eob = e > eob ? e : eob;
+            qsum += (uint32_t)(qv > 63 ? 63 : qv);
+            const int32_t dd = a - dq; // == |coeff - dqcoeff|: both carry the coefficient's sign
+            dres += (u64)(uint32_t)__mul24(dd, dd);
+            dpred += (u64)(uint32_t)__umul24((uint32_t)a, (uint32_t)a);
+            A[r * PB + c] = dqs;
+            if (q_out) q_out[rc] = qs;
+            return qs;
+        };
+        const int ac0 = l != 0;
+        dc_q = one(l, zb_c[ac0], rnd_c[ac0], q.quant[ac0], q.quant_shift[ac0], q.dequant[ac0]);
+        const int32_t zb1 = zb_c[1], rnd1 = rnd_c[1], quant1 = q.quant[1], qshift1 = q.quant_shift[1], deq1 = q.dequant[1];
+#pragma unroll 4
+        for (int rc = l + LW; rc < NP; rc += LW) one(rc, zb1, rnd1, quant1, qshift1, deq1);
+    } else
     for (int rc = l; rc < NP; rc += LW) {
         const int r = rc / WP, c = rc - r * WP, ac = rc != 0;
         const bool kept = pf == 0 || (c < keep_w && r < keep_h);
