@@ -538,34 +538,75 @@ def other_kernels(ctx, wl, ext):
         return np.concatenate(js)
 
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+
+    def hier(w, h, jobs):
+        """the same tiling as hierarchical work: the full 64x64 regions as pyramid jobs (85 nested blocks each from one read of the region),
+        the blocks outside them as plain jobs; slot of every flat job in the hierarchical output arrays (for the equality check)"""
+        full_w, full_h = (w // 64) * 64, (h // 64) * 64
+        ys, xs = (jobs["src_offset"] // w).astype(np.int64), (jobs["src_offset"] % w).astype(np.int64)
+        inside = (xs + jobs["width"] <= full_w) & (ys + jobs["height"] <= full_h)
+        plain = np.ascontiguousarray(jobs[~inside])
+        ry, rx = np.meshgrid(np.arange(0, full_h, 64), np.arange(0, full_w, 64), indexing="ij")
+        reg = np.zeros(ry.size, dtype=abi.BLOCK_JOB_DTYPE)
+        reg["src_offset"] = reg["ref_offset"] = (ry.ravel() * w + rx.ravel()).astype(np.uint32)
+        reg["width"] = reg["height"] = 64
+        slot = np.zeros(len(jobs), np.int64)
+        slot[~inside] = np.arange(len(plain))
+        n = jobs["width"].astype(np.int64)
+        level_base = {64: 0, 32: 1, 16: 5, 8: 21}
+        k = (ys // 64) * (full_w // 64) + xs // 64
+        per = 64 // np.maximum(n, 1)
+        z = np.array([level_base.get(int(v), 0) for v in n]) + ((ys % 64) // np.maximum(n, 1)) * per + (xs % 64) // np.maximum(n, 1)
+        slot[inside] = (len(plain) + abi.PYRAMID_BLOCKS * k + z)[inside]
+        return plain, reg, slot
+
+    def both(tag, w, h, jobs, desc_kw, fields, bytes_per_px, extra=None):
+        """flat job list vs hierarchical jobs of the same tiling: timings, and the outputs must be identical"""
+        n = len(jobs)
+        t_j = dev(jobs)
+        o = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in fields}
+        d = abi.BlockStatsDesc(n_jobs=n, jobs=t_j.data_ptr(), **desc_kw)
+        if extra:
+            d.pred_mode, d.compound_type = extra[0].data_ptr(), extra[1].data_ptr()
+        for name, _ in fields:
+            setattr(d, name, o[name].data_ptr())
+        ms_flat = timeit(lambda: ctx.check(L.svt_hip_block_stats_batch(ctx._h, C.byref(d)), "block_stats"))
+        plain, reg, slot = hier(w, h, jobs)
+        nh = len(plain) + abi.PYRAMID_BLOCKS * len(reg)
+        t_p, t_r = dev(plain if len(plain) else np.zeros(1, abi.BLOCK_JOB_DTYPE)), dev(reg)
+        oh = {name: torch.zeros(nh * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in fields}
+        dh = abi.BlockStatsDesc(n_jobs=len(plain), jobs=t_p.data_ptr(), n_pyramids=len(reg), pyramid_out_base=len(plain), pyramids=t_r.data_ptr(), **desc_kw)
+        if extra:  # the per-candidate arrays follow the outputs' slot order
+            sl = torch.from_numpy(slot).cuda()
+            em = [torch.zeros(nh, dtype=torch.uint8, device="cuda") for _ in extra]
+            for dst, src_t in zip(em, extra):
+                dst[sl] = src_t
+            dh.pred_mode, dh.compound_type = em[0].data_ptr(), em[1].data_ptr()
+        for name, _ in fields:
+            setattr(dh, name, oh[name].data_ptr())
+        ms = timeit(lambda: ctx.check(L.svt_hip_block_stats_batch(ctx._h, C.byref(dh)), "block_stats"))
+        same = all(np.array_equal(oh[name].cpu().numpy().view(dt)[slot], o[name].cpu().numpy().view(dt)) for name, dt in fields)
+        px = int((jobs["width"].astype(np.int64) * jobs["height"]).sum())
+        uniq = w * h * bytes_per_px // 4  # every sample of the two planes once
+        out[tag] = {"ms": round(ms, 4), "flat_ms": round(ms_flat, 4), "speedup_vs_flat_jobs": round(ms_flat / ms, 2), "outputs_identical_to_flat_jobs": bool(same),
+                    "gb_s": round(uniq / ms / 1e6, 1), "bytes": int(uniq), "flat_bytes": px * bytes_per_px // 4 * 1, "jobs": n, "pyramids": len(reg), "plain_jobs": len(plain),
+                    "what": "hierarchical jobs: a wave per 64x64 region emits its 85 nested blocks from one read; `bytes` = the two planes once; flat = one job per block (every size re-reads its samples)"}
+
     # -- config 2: 1080p 8-bit block statistics incl. Hadamard
     y8 = synth.to_8bit(s0.y10_host[CUR:CUR + 2, :1080, :1920])
     jobs = tiling(1920, 1080, [(64, 64), (32, 32), (16, 16), (8, 8)])
-    n = len(jobs)
-    t_s, t_r, t_j = dev(y8[1]), dev(y8[0]), dev(jobs)
-    o = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in abi.STATS_OUT_FIELDS}
-    d = abi.BlockStatsDesc(bit_depth=8, n_jobs=n, src_stride=1920, ref_stride=1920, src=t_s.data_ptr(), ref=t_r.data_ptr(), jobs=t_j.data_ptr())
-    for name, _ in abi.STATS_OUT_FIELDS:
-        setattr(d, name, o[name].data_ptr())
-    ms = timeit(lambda: ctx.check(L.svt_hip_block_stats_batch(ctx._h, C.byref(d)), "block_stats"))
-    px = int((jobs["width"].astype(np.int64) * jobs["height"]).sum())
-    out["block_stats_1080p8 (sad+sse+var+hadamard, 8x8..64x64)"] = {"ms": round(ms, 4), "gb_s": round(px * 2 / ms / 1e6, 1), "bytes": px * 2, "jobs": n}
+    t_s, t_r = dev(y8[1]), dev(y8[0])
+    both("block_stats_1080p8 (sad+sse+var+hadamard, 8x8..64x64)", 1920, 1080, jobs, dict(bit_depth=8, src_stride=1920, ref_stride=1920, src=t_s.data_ptr(), ref=t_r.data_ptr()),
+         list(abi.STATS_OUT_FIELDS), 8)
     # -- config 5: 2160p 10-bit psy-RD + facade
     jobs = tiling(W, H, [(64, 64), (32, 32), (16, 16), (8, 8)])
     n = len(jobs)
-    t_j = dev(jobs)
     rng = np.random.default_rng(5)
     t_mode, t_comp = dev(rng.integers(0, 25, n).astype(np.uint8)), dev(rng.integers(0, 4, n).astype(np.uint8))
-    fields = list(abi.STATS_OUT_FIELDS) + list(abi.PSY_OUT_FIELDS) + list(abi.FACADE_OUT_FIELDS) + list(abi.VAR10_OUT_FIELDS)
-    o = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in fields}
-    d = abi.BlockStatsDesc(bit_depth=10, n_jobs=n, src_stride=W, ref_stride=W, src=s0.src10.data_ptr(), ref=s0.y10[CUR - 1].data_ptr(), jobs=t_j.data_ptr(), psy_rd=1.35,
-                           temporal_layer_index=2, spy_rd=1, pred_mode=t_mode.data_ptr(), compound_type=t_comp.data_ptr())
-    for name, _ in fields:
-        if name != "satd":
-            setattr(d, name, o[name].data_ptr())
-    ms = timeit(lambda: ctx.check(L.svt_hip_block_stats_batch(ctx._h, C.byref(d)), "block_stats"))
-    px = int((jobs["width"].astype(np.int64) * jobs["height"]).sum())
-    out["psy_rd_2160p10 (sse+var10+psy+facade, 8x8..64x64)"] = {"ms": round(ms, 4), "gb_s": round(px * 4 / ms / 1e6, 1), "bytes": px * 4, "jobs": n}
+    fields = [f for f in list(abi.STATS_OUT_FIELDS) + list(abi.PSY_OUT_FIELDS) + list(abi.FACADE_OUT_FIELDS) + list(abi.VAR10_OUT_FIELDS) if f[0] != "satd"]
+    both("psy_rd_2160p10 (sse+var10+psy+facade, 8x8..64x64)", W, H, jobs,
+         dict(bit_depth=10, src_stride=W, ref_stride=W, src=s0.src10.data_ptr(), ref=s0.y10[CUR - 1].data_ptr(), psy_rd=1.35, temporal_layer_index=2, spy_rd=1), fields, 16,
+         extra=(t_mode, t_comp))
     # -- dynamic-GOP detector HME on a 2160p pair
     m = torch.zeros(64, dtype=torch.uint8, device="cuda")
     a, b = s0.pics[CUR], s0.pics[CUR - 1]

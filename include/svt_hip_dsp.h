@@ -158,7 +158,17 @@ typedef struct SvtHipBlockStatsDesc {
     /* svt_aom_highbd_10_variance{W}x{H}_c (Codec/svt_psnr.c:139-177), 10-bit planes only: sse and sum are brought back to the
      * 8-bit scale with rounding ((sse + 8) >> 4, (sum + 2) >> 2) before sse - sum^2 / (w*h), clamped at 0 */
     uint32_t *variance10, *var_sse10;
+    /* Optional hierarchical jobs: `n_pyramids` 64x64 regions (device array `pyramids`; width = height = 64, no sub-pixel view).  One wave
+     * reads a region's samples ONCE and produces the outputs of its 85 nested square blocks -- the 64x64, its 4 32x32, 16 16x16 and 64 8x8
+     * blocks, each level in raster order: SAD / sum / SSE (hence every variance and facade output) and the PSYEX psy energy (a sum over
+     * 8x8 tiles for every block size, psy_rd.c:135-274) add up the tree; hadamard_path's SATD is evaluated per size from one staged
+     * residual (a 64x64 SATD is the sum of its four 32x32 tiles', enc_mode_config.c:2151-2217).  Region k writes output slots
+     * pyramid_out_base + 85 k .. + 84 of the same output arrays (pred_mode / compound_type are read at those slots); plain jobs keep
+     * slots 0 .. n_jobs - 1.  Results are those of 85 plain jobs. */
+    uint32_t              n_pyramids, pyramid_out_base;
+    const SvtHipBlockJob *pyramids;
 } SvtHipBlockStatsDesc;
+#define SVT_HIP_PYRAMID_BLOCKS 85
 
 /* The integer biases svt_spatial_full_distortion_kernel_facade applies to an SSE (picture_operators_c.c:130-171): host-only
  * arithmetic, for callers that already hold the SSE (e.g. SvtHipRdBatchDesc.sse).  mode / compound_type are the reference's

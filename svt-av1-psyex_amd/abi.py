@@ -179,9 +179,11 @@ class BlockStatsDesc(C.Structure):
                 ("sad", C.c_void_p), ("sse", C.c_void_p), ("variance", C.c_void_p), ("var_sse", C.c_void_p), ("satd", C.c_void_p),
                 ("psy_rd", C.c_double), ("psy_energy", C.c_void_p), ("psy_dist", C.c_void_p),
                 ("psy_sse", C.c_void_p), ("pred_mode", C.c_void_p), ("compound_type", C.c_void_p), ("facade_dist", C.c_void_p),
-                ("variance10", C.c_void_p), ("var_sse10", C.c_void_p)]
+                ("variance10", C.c_void_p), ("var_sse10", C.c_void_p),
+                ("n_pyramids", C.c_uint32), ("pyramid_out_base", C.c_uint32), ("pyramids", C.c_void_p)]
 
 
+PYRAMID_BLOCKS = 85  # nested square blocks of a 64x64 region: 1 + 4 + 16 + 64, each level in raster order
 BLOCK_JOB_DTYPE = [("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("subpel_x", "u1"), ("subpel_y", "u1")]
 STATS_OUT_FIELDS = [("sad", "<u4"), ("sse", "<u8"), ("variance", "<u4"), ("var_sse", "<u4"), ("satd", "<u4")]
 PSY_OUT_FIELDS = [("psy_energy", "<u8"), ("psy_dist", "<u8"), ("psy_sse", "<u8")]

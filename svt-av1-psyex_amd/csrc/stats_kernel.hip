@@ -563,6 +563,172 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         }
 }
 
+// ---- hierarchical block statistics: one workgroup <-> one 64x64 region.  The region's samples are read once for the pixel statistics (and once
+// more, as residuals into the LDS tiles, for hadamard_path); the sums of the nested blocks are DPP reductions.  Output slot of nested block z:
+// out0 + z with z = 0 (64x64), 1 + raster (32x32), 5 + raster (16x16), 21 + raster (8x8).
+__device__ __forceinline__ uint32_t quad_sum_u32(uint32_t v) { // sum over the 4 lanes of a quad, in all of them
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    return v + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t row16_sum_of_quads(uint32_t v) { // v uniform inside each quad: sum of the 4 quads of a 16-lane row, in all 16 lanes
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true);
+    return v + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140 /* row_mirror */, 0xF, 0xF, true);
+}
+// Without hadamard_path (the psy / facade batches): ONE wave per region, lane <-> one 8x8 block in Morton order (one psy tile per lane: every
+// lane busy in the tile transforms), 16x16 = quad, 32x32 = 16-lane row, 64x64 = the wave.
+template <typename Pix> __global__ void __launch_bounds__(64) block_stats_pyramid1_kernel(const StatsParams p) {
+    const int      lane = threadIdx.x;
+    const uint32_t reg = blockIdx.x, out0 = p.d.pyramid_out_base + SVT_HIP_PYRAMID_BLOCKS * reg;
+    const SvtHipBlockJob jb = p.d.pyramids[reg];
+    const Pix *src = static_cast<const Pix *>(p.d.src) + jb.src_offset, *ref = static_cast<const Pix *>(p.d.ref) + jb.ref_offset;
+    // lane -> 8x8 block coordinates: bits x0 y0 x1 y1 x2 y2
+    const int bx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), by = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    uint32_t sad = 0, sq = 0;
+    int32_t  sum = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const Pix *s = src + (size_t)(8 * by + r) * p.d.src_stride + 8 * bx, *q = ref + (size_t)(8 * by + r) * p.d.ref_stride + 8 * bx;
+        quad_stats(s, q, sad, sum, sq);
+        quad_stats(s + 4, q + 4, sad, sum, sq);
+    }
+    const bool psy = p.d.psy_energy || p.d.psy_dist || (p.d.psy_sse && p.d.psy_rd > 0.0);
+    uint32_t e8 = 0; // |energy(src tile) - energy(ref tile)| of this lane's 8x8 tile
+    if (psy) { // uniform
+        const View<Pix> sv = {src + (size_t)(8 * by) * p.d.src_stride + 8 * bx, p.d.src_stride, 0, 0}, rv = {ref + (size_t)(8 * by) * p.d.ref_stride + 8 * bx, p.d.ref_stride, 0, 0};
+        const int32_t a = psy_tile_energy<Pix>(sv, 8), b = psy_tile_energy<Pix>(rv, 8);
+        e8 = (uint32_t)(a > b ? a - b : b - a);
+    }
+    const uint32_t sad16 = quad_sum_u32(sad), sq16 = quad_sum_u32(sq), e16 = quad_sum_u32(e8);
+    const int32_t  sum16 = (int32_t)quad_sum_u32((uint32_t)sum);
+    const uint32_t sad32 = row16_sum_of_quads(sad16), sq32 = row16_sum_of_quads(sq16), e32 = row16_sum_of_quads(e16); // a 32x32 block: 1024 x 1023^2 < 2^32
+    const int32_t  sum32 = (int32_t)row16_sum_of_quads((uint32_t)sum16);
+    const uint32_t sad64 = wave_sum_dpp(sad), e64lo = wave_sum_dpp(e8 & 0xFFFFu), e64hi = wave_sum_dpp(e8 >> 16);
+    const int32_t  sum64 = (int32_t)wave_sum_dpp((uint32_t)sum);
+    const u64      sse64 = (u64)wave_sum_dpp(sq & 0xFFFFu) + ((u64)wave_sum_dpp(sq >> 16) << 16), e64 = (u64)e64lo + ((u64)e64hi << 16);
+    auto emit = [&](uint32_t slot, int n, uint32_t a_sad, int32_t a_sum, u64 a_sse, u64 a_e) {
+        write_pixel_outputs(p, slot, n, n, a_sad, a_sum, a_sse);
+        const u64 e = sizeof(Pix) == 1 ? a_e >> 1 : a_e << 2;
+        if (psy) {
+            if (p.d.psy_energy) p.d.psy_energy[slot] = e;
+            if (p.d.psy_dist) p.d.psy_dist[slot] = (u64)((double)e * p.d.psy_rd);
+            if (p.d.psy_sse) p.d.psy_sse[slot] = a_sse + (u64)((double)e * p.d.psy_rd);
+        } else if (p.d.psy_sse) p.d.psy_sse[slot] = a_sse;
+    };
+    emit(out0 + 21 + 8 * by + bx, 8, sad, sum, sq, e8);
+    if ((lane & 3) == 0) emit(out0 + 5 + 4 * (by >> 1) + (bx >> 1), 16, sad16, sum16, sq16, e16);
+    if ((lane & 15) == 0) emit(out0 + 1 + 2 * (by >> 2) + (bx >> 2), 32, sad32, sum32, sq32, e32);
+    if (lane == 0) emit(out0, 64, sad64, sum64, sse64, e64);
+}
+
+// With hadamard_path -- four waves per region: wave q <-> 32x32 quadrant q (raster), lane <-> (8x8 block of the quadrant in Morton order, pair of rows): the 8x8 sums are
+// quad sums, the 16x16 sums 16-lane row sums, the 32x32 sums wave sums, the 64x64 sums meet in LDS.  Each wave stages its own quadrant's
+// residuals once for hadamard_path's 8x8 / 16x16 / 32x32 SATDs.
+struct PyrLds {
+    int16_t  res[4][32 * kResPitch];
+    uint32_t sad[4], e_lo[4], e_hi[4], satd[4];
+    int32_t  sum[4];
+    u64      sse[4];
+};
+template <typename Pix> __global__ void __launch_bounds__(256) block_stats_pyramid_kernel(const StatsParams p) {
+    __shared__ PyrLds S;
+    const int      lane = threadIdx.x & 63, q = threadIdx.x >> 6, qy = q >> 1, qx = q & 1;
+    const uint32_t reg = blockIdx.x, out0 = p.d.pyramid_out_base + SVT_HIP_PYRAMID_BLOCKS * reg;
+    const SvtHipBlockJob jb = p.d.pyramids[reg];
+    const Pix *src = static_cast<const Pix *>(p.d.src) + jb.src_offset + (size_t)(32 * qy) * p.d.src_stride + 32 * qx;
+    const Pix *ref = static_cast<const Pix *>(p.d.ref) + jb.ref_offset + (size_t)(32 * qy) * p.d.ref_stride + 32 * qx;
+    // lane = blk * 4 + row pair; blk bits x0 y0 x1 y1 -> 8x8 block (bx, by) of the quadrant
+    const int blk = lane >> 2, rp = lane & 3, bx = (blk & 1) | ((blk >> 1) & 2), by = ((blk >> 1) & 1) | ((blk >> 2) & 2);
+    uint32_t sad = 0, sq = 0;
+    int32_t  sum = 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const Pix *sp = src + (size_t)(8 * by + 2 * rp + r) * p.d.src_stride + 8 * bx, *qp = ref + (size_t)(8 * by + 2 * rp + r) * p.d.ref_stride + 8 * bx;
+        quad_stats(sp, qp, sad, sum, sq);
+        quad_stats(sp + 4, qp + 4, sad, sum, sq);
+    }
+    const bool psy = p.d.psy_energy || p.d.psy_dist || (p.d.psy_sse && p.d.psy_rd > 0.0);
+    uint32_t e8 = 0; // |energy(src tile) - energy(ref tile)| of the block's 8x8 tile: computed by the block's first lane, zero in the others
+    if (psy && rp == 0) {
+        const View<Pix> sv = {src + (size_t)(8 * by) * p.d.src_stride + 8 * bx, p.d.src_stride, 0, 0}, rv = {ref + (size_t)(8 * by) * p.d.ref_stride + 8 * bx, p.d.ref_stride, 0, 0};
+        const int32_t a = psy_tile_energy<Pix>(sv, 8), b = psy_tile_energy<Pix>(rv, 8);
+        e8 = (uint32_t)(a > b ? a - b : b - a);
+    }
+    // the tree: 8x8 = quad, 16x16 = 16-lane row, 32x32 = the wave, 64x64 = the four waves
+    const uint32_t sad8 = quad_sum_u32(sad), sq8 = quad_sum_u32(sq), e8s = quad_sum_u32(e8);
+    const int32_t  sum8 = (int32_t)quad_sum_u32((uint32_t)sum);
+    const uint32_t sad16 = row16_sum_of_quads(sad8), sq16 = row16_sum_of_quads(sq8), e16 = row16_sum_of_quads(e8s);
+    const int32_t  sum16 = (int32_t)row16_sum_of_quads((uint32_t)sum8);
+    const uint32_t sad32 = wave_sum_dpp(sad), sq32 = wave_sum_dpp(sq), e32lo = wave_sum_dpp(e8 & 0xFFFFu), e32hi = wave_sum_dpp(e8 >> 16); // 1024 x 1023^2 < 2^32
+    const int32_t  sum32 = (int32_t)wave_sum_dpp((uint32_t)sum);
+    auto emit = [&](uint32_t slot, int n, uint32_t a_sad, int32_t a_sum, u64 a_sse, u64 a_e) {
+        write_pixel_outputs(p, slot, n, n, a_sad, a_sum, a_sse);
+        const u64 e = sizeof(Pix) == 1 ? a_e >> 1 : a_e << 2;
+        if (psy) {
+            if (p.d.psy_energy) p.d.psy_energy[slot] = e;
+            if (p.d.psy_dist) p.d.psy_dist[slot] = (u64)((double)e * p.d.psy_rd);
+            if (p.d.psy_sse) p.d.psy_sse[slot] = a_sse + (u64)((double)e * p.d.psy_rd);
+        } else if (p.d.psy_sse) p.d.psy_sse[slot] = a_sse;
+    };
+    if (rp == 0) emit(out0 + 21 + 8 * (4 * qy + by) + 4 * qx + bx, 8, sad8, sum8, sq8, e8s);
+    if ((lane & 15) == 0) emit(out0 + 5 + 4 * (2 * qy + (by >> 1)) + 2 * qx + (bx >> 1), 16, sad16, sum16, sq16, e16);
+    if (lane == 0) {
+        emit(out0 + 1 + q, 32, sad32, sum32, sq32, (u64)e32lo + ((u64)e32hi << 16));
+        S.sad[q] = sad32; S.sum[q] = sum32; S.sse[q] = sq32; S.e_lo[q] = e32lo; S.e_hi[q] = e32hi;
+    }
+    uint32_t s32 = 0;
+    if (p.d.satd) { // uniform; 8-bit planes (checked by the host): hadamard_path of the quadrant's nested blocks from one staged residual
+        const had_half4 h = had16_weights(lane);
+        HadLds &L = *reinterpret_cast<HadLds *>(S.res[q]); // only .res is touched by the matrix-core path
+        for (int i = lane; i < 256; i += 64) {
+            const int r = i >> 3, c = 4 * (i & 7);
+            quad_residual(src + (size_t)r * p.d.src_stride + c, ref + (size_t)r * p.d.ref_stride + c, &L.res[r * kResPitch + c]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier(); // a wave's own LDS writes are ordered before its later reads; only this wave touches its tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int32_t  o[4][4];
+        uint32_t sv8[4], sv16[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) { // the quadrant's 16x16 blocks: their four 8x8 SATDs, then their own (the sums are reduced together below)
+            int32_t y[4];
+            had8x4_mfma(L, sb >> 1, sb & 1, lane, h, y);
+            sv8[sb] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) sv8[sb] += (uint32_t)(y[j] < 0 ? -y[j] : y[j]);
+            had16_mfma(L, sb >> 1, sb & 1, lane, h, o[sb]);
+            sv16[sb] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) sv16[sb] += (uint32_t)(o[sb][j] < 0 ? -o[sb][j] : o[sb][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { // svt_aom_hadamard_32x32_c's combine of the four 16x16 transforms (picture_operators_c.c:299-326), as hadamard_satd_mfma
+            const int b0 = (o[0][j] + o[1][j]) >> 2, b1 = (o[0][j] - o[1][j]) >> 2, b2 = (o[2][j] + o[3][j]) >> 2, b3 = (o[2][j] - o[3][j]) >> 2;
+            const int c0 = b0 + b2, c1 = b1 + b3, c2 = b0 - b2, c3 = b1 - b3;
+            s32 += (uint32_t)(c0 < 0 ? -c0 : c0) + (uint32_t)(c1 < 0 ? -c1 : c1) + (uint32_t)(c2 < 0 ? -c2 : c2) + (uint32_t)(c3 < 0 ? -c3 : c3);
+        }
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+            // 8x8 block (k0 / 8, r / 8) = (lane bit 5, lane bit 3) of the 16x16: sum over the other four lane bits
+            uint32_t sv = sv8[sb];
+            sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64); sv += __shfl_xor(sv, 16, 64);
+            if ((lane & 23) == 0) p.d.satd[out0 + 21 + 8 * (4 * qy + 2 * (sb >> 1) + (lane >> 5)) + 4 * qx + 2 * (sb & 1) + ((lane >> 3) & 1)] = sv;
+            const uint32_t s16 = wave_sum_dpp(sv16[sb]);
+            if (lane == 0) p.d.satd[out0 + 5 + 4 * (2 * qy + (sb >> 1)) + 2 * qx + (sb & 1)] = s16;
+        }
+        s32 = wave_sum_dpp(s32);
+        if (lane == 0) { p.d.satd[out0 + 1 + q] = s32; S.satd[q] = s32; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // the 64x64 block
+        u64 sse = 0, e = 0;
+        uint32_t sd = 0, st = 0;
+        int32_t  sm = 0;
+        for (int k = 0; k < 4; k++) { sse += S.sse[k]; e += (u64)S.e_lo[k] + ((u64)S.e_hi[k] << 16); sd += S.sad[k]; sm += S.sum[k]; st += S.satd[k]; }
+        emit(out0, 64, sd, sm, sse, e);
+        if (p.d.satd) p.d.satd[out0] = st; // hadamard_path_c: a 64x64 block is four 32x32 tiles
+    }
+}
+
 // ---- svt_sad_loop_kernel: one thread per search position, first minimum in raster order through a 64-bit key ------
 struct SadLoopParams {
     const uint8_t *src, *ref;
@@ -684,9 +850,10 @@ extern "C" {
 
 int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d) {
     if (!ctx || !d) return SVT_HIP_ERR_BAD_PARAM;
-    if (d->n_jobs == 0) return SVT_HIP_OK;
+    if (d->n_jobs == 0 && d->n_pyramids == 0) return SVT_HIP_OK;
     if (d->bit_depth != 8 && d->bit_depth != 10) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "bit_depth %u", d->bit_depth);
-    if (!d->src || !d->ref || !d->jobs) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the block-stats batch is null");
+    if (!d->src || !d->ref || (d->n_jobs && !d->jobs) || (d->n_pyramids && !d->pyramids))
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "a mandatory pointer of the block-stats batch is null");
     if (d->satd && d->bit_depth != 8) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "hadamard_path works on 8-bit input (enc_mode_config.c:2186)");
     if ((d->variance10 || d->var_sse10) && d->bit_depth != 10) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "variance10 is defined on 10-bit planes");
     if (d->facade_dist && (!d->pred_mode || !d->compound_type || d->temporal_layer_index > 5))
@@ -695,8 +862,15 @@ int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d)
     StatsParams p;
     p.d = *d;
     const uint32_t grid = (d->n_jobs + kJobsPerWave - 1) / kJobsPerWave;
-    if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_kernel<uint8_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
-    else hipLaunchKernelGGL(block_stats_kernel<uint16_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
+    if (grid) {
+        if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_kernel<uint8_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
+        else hipLaunchKernelGGL(block_stats_kernel<uint16_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
+    }
+    if (d->n_pyramids) {
+        if (d->satd) hipLaunchKernelGGL(block_stats_pyramid_kernel<uint8_t>, dim3(d->n_pyramids), dim3(256), 0, ctx->stream, p); // (8-bit planes: checked above)
+        else if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_pyramid1_kernel<uint8_t>, dim3(d->n_pyramids), dim3(64), 0, ctx->stream, p);
+        else hipLaunchKernelGGL(block_stats_pyramid1_kernel<uint16_t>, dim3(d->n_pyramids), dim3(64), 0, ctx->stream, p);
+    }
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }

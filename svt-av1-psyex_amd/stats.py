@@ -24,17 +24,36 @@ def random_jobs(rng, plane_w, plane_h, n, sizes=None, square_only=False, subpel=
     return jobs
 
 
-def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None, facade=None):
-    """facade: dict(pred_mode=u8[n], compound_type=u8[n], temporal_layer_index=int, spy_rd=int) -> also `facade_dist`."""
+def expand_pyramid(region, src_stride, ref_stride):
+    """the 85 plain jobs a hierarchical 64x64 region stands for, in its output-slot order: 64x64, 4 x 32x32, 16 x 16x16, 64 x 8x8, each level
+    in raster order (SvtHipBlockStatsDesc.pyramids)"""
+    out = np.zeros(abi.PYRAMID_BLOCKS, dtype=abi.BLOCK_JOB_DTYPE)
+    k = 0
+    for n in (64, 32, 16, 8):
+        for y in range(0, 64, n):
+            for x in range(0, 64, n):
+                out[k] = (int(region["src_offset"]) + y * src_stride + x, int(region["ref_offset"]) + y * ref_stride + x, n, n, 0, 0)
+                k += 1
+    return out
+
+
+def run_hip(ctx, src, ref, jobs, bit_depth, satd=True, psy_rd=None, facade=None, pyramids=None):
+    """facade: dict(pred_mode=u8[n], compound_type=u8[n], temporal_layer_index=int, spy_rd=int) -> also `facade_dist`.
+    pyramids: optional array of 64x64 region jobs; their 85 outputs each follow the plain jobs' (slots len(jobs) + 85 k ...; the facade
+    arrays then cover those slots too)."""
     import torch
     from . import api
     L = api.lib()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
-    n = len(jobs)
-    t_src, t_ref, t_jobs = dev(src), dev(ref), dev(jobs)
+    n_plain = len(jobs)
+    n = n_plain + (abi.PYRAMID_BLOCKS * len(pyramids) if pyramids is not None else 0)
+    t_src, t_ref, t_jobs = dev(src), dev(ref), dev(jobs if n_plain else np.zeros(1, abi.BLOCK_JOB_DTYPE))
     fields = list(abi.STATS_OUT_FIELDS) + (list(abi.PSY_OUT_FIELDS) if psy_rd is not None else []) + (list(abi.FACADE_OUT_FIELDS) if facade else []) + (list(abi.VAR10_OUT_FIELDS) if bit_depth == 10 else [])
     outs = {name: torch.zeros(n * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda") for name, dt in fields}
-    d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1])
+    d = abi.BlockStatsDesc(bit_depth=bit_depth, n_jobs=n_plain, src_stride=src.shape[1], ref_stride=ref.shape[1])
+    if pyramids is not None and len(pyramids):
+        t_pyr = dev(pyramids)
+        d.n_pyramids, d.pyramid_out_base, d.pyramids = len(pyramids), n_plain, t_pyr.data_ptr()
     if psy_rd is not None:
         d.psy_rd = psy_rd
         for name, _ in abi.PSY_OUT_FIELDS:

@@ -423,3 +423,50 @@ def test_leaf_cul_level_and_fwht4x4(leaf, oracle):
         leaf.svt_av1_fwht4x4_hip(p(src), p(a), C.c_uint32(stride))
         oracle.orc_fwht4x4(p(src), p(b), C.c_uint32(stride))
         assert np.array_equal(a, b), trial
+
+
+# ---- hierarchical jobs: a 64x64 region's 85 nested blocks from one read of its samples (SvtHipBlockStatsDesc.pyramids) ----
+def _regions(rng, w, h, n):
+    reg = np.zeros(n, dtype=abi.BLOCK_JOB_DTYPE)
+    for i in range(n):
+        x0, y0, x1, y1 = rng.integers(0, w - 63), rng.integers(0, h - 63), rng.integers(0, w - 63), rng.integers(0, h - 63)
+        reg[i] = (y0 * w + x0, y1 * w + x1, 64, 64, 0, 0)
+    return reg
+
+
+def test_pyramid_jobs_8bit_equal_plain_jobs_and_oracle(hip_ctx, oracle):
+    rng = np.random.default_rng(77)
+    w, h = 416, 240
+    src = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ref = np.clip(src.astype(np.int32) + rng.integers(-30, 31, src.shape), 0, 255).astype(np.uint8)
+    ref[:64, :64] = 255 - src[:64, :64]  # a region of large residuals
+    reg = _regions(rng, w, h, 23)
+    reg[0] = (0, 0, 64, 64, 0, 0)
+    plain = stats.random_jobs(rng, w, h, 50, square_only=True)
+    expanded = np.concatenate([plain] + [stats.expand_pyramid(r, w, w) for r in reg])
+    want = pyoracle.block_stats(oracle, src, ref, expanded, 8, psy_rd=0.75)
+    flat = stats.run_hip(hip_ctx, src, ref, expanded, 8, psy_rd=0.75)
+    got = stats.run_hip(hip_ctx, src, ref, plain, 8, psy_rd=0.75, pyramids=reg)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=f"{k} vs oracle")
+        np.testing.assert_array_equal(got[k], flat[k], err_msg=f"{k} vs plain jobs")
+    nosatd = stats.run_hip(hip_ctx, src, ref, plain, 8, satd=False, psy_rd=0.75, pyramids=reg)  # without hadamard_path: the one-wave form
+    for k in nosatd:
+        np.testing.assert_array_equal(nosatd[k], want[k], err_msg=f"{k} (no SATD) vs oracle")
+
+
+def test_pyramid_jobs_10bit_psy_facade(hip_ctx, oracle):
+    rng = np.random.default_rng(78)
+    w, h = 320, 192
+    src = rng.integers(0, 1024, (h, w)).astype(np.uint16)
+    ref = np.clip(src.astype(np.int32) + rng.integers(-90, 91, src.shape), 0, 1023).astype(np.uint16)
+    ref[64:128, 64:128] = 1023 - src[64:128, 64:128]
+    reg = _regions(rng, w, h, 17)
+    reg[0] = (64 * w + 64, 64 * w + 64, 64, 64, 0, 0)
+    expanded = np.concatenate([stats.expand_pyramid(r, w, w) for r in reg])
+    n = len(expanded)
+    facade = dict(pred_mode=rng.integers(0, 25, n).astype(np.uint8), compound_type=rng.integers(0, 4, n).astype(np.uint8), temporal_layer_index=3, spy_rd=1)
+    want = pyoracle.block_stats(oracle, src, ref, expanded, 10, satd=False, psy_rd=1.35, facade=facade)
+    got = stats.run_hip(hip_ctx, src, ref, np.zeros(0, abi.BLOCK_JOB_DTYPE), 10, satd=False, psy_rd=1.35, facade=facade, pyramids=reg)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
