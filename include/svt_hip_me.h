@@ -187,6 +187,12 @@ int   svt_hip_context_set_me_waves_per_cu(SvtHipContext *ctx, uint32_t waves);
  * :820-920) of every block -- searches whose windows depend on the block position and the picture distance only -- are made by a kernel of
  * their own ahead of the per-block kernel, which takes their results instead of searching.  Results are identical either way. */
 int   svt_hip_context_set_me_dense(SvtHipContext *ctx, int on);
+/* With the pre-pass on, the per-block pipeline can run STAGED: a chain of small kernels cut at its searches (control / level-1 searches / control /
+ * level-2 searches / integer search and outputs), a block's state travelling through HBM between them -- each kernel has the register and
+ * LDS budget of its own part only.  Blocks whose pre-HME / level-0 searches the pre-pass did not make go through the one-kernel form at the
+ * end of the launch.  on = 0: never; 1 (default): launches of 4096 blocks and more (a small launch is latency-bound: one kernel serves it
+ * better than nine); 2: every launch.  SVT_HIP_ME_STAGED=0/1/2 sets it at context creation.  Results are identical either way. */
+int   svt_hip_context_set_me_staged(SvtHipContext *ctx, int on);
 /* Diagnostics: out[0] = searches the per-block kernel took from the pre-pass, out[1] = searches it made itself although the pre-pass was
  * on (edge blocks, configurations the pre-pass does not cover), since the last call; waits for the context's streams. */
 int   svt_hip_me_dense_counters(SvtHipContext *ctx, unsigned long long out[2]);

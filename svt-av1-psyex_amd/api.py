@@ -114,6 +114,10 @@ class Context:
         """the dense pre-HME / HME level-0 pre-pass of the ME launches (svt_hip_context_set_me_dense); results are identical either way"""
         self.check(lib().svt_hip_context_set_me_dense(self._h, 1 if on else 0), "svt_hip_context_set_me_dense")
 
+    def set_me_staged(self, on):
+        """with the pre-pass on: the per-block pipeline as a chain of small kernels (svt_hip_context_set_me_staged): 0 never, 1 launches of many blocks (default), 2 always; results are identical either way"""
+        self.check(lib().svt_hip_context_set_me_staged(self._h, int(on)), "svt_hip_context_set_me_staged")
+
     def me_dense_counters(self):
         """(searches taken from the dense pre-pass, searches the per-block kernel made itself) since the last call"""
         v = (C.c_ulonglong * 2)()

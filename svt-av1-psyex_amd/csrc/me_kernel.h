@@ -131,6 +131,26 @@ struct MeDenseEntry {
 };
 #define SVT_HIP_ME_DENSE_MAX_ENTRIES (SVT_HIP_ME_MAX_PICTURES * SVT_HIP_MAX_LISTS * SVT_HIP_MAX_REFS * SVT_HIP_ME_DENSE_KINDS)
 
+// Staged launches (me_kernel.hip): per job a record in HBM -- the head of the block's state, its search requests, their results -- and a flag word
+#define SVT_HIP_ME_STAGE_BYTES 2560
+#define SVT_HIP_ME_JOB_DEFERRED 1u /* a search the pre-pass did not make: the whole-pipeline kernel makes the block (list 0) */
+#define SVT_HIP_ME_JOB_STAGED1 2u  /* its level-1 searches need the staged form (list 1) */
+#define SVT_HIP_ME_JOB_STAGED2 4u  /* its level-2 searches need the staged form (list 2) */
+/* u32 indices into a lane's queue_head block (2 KiB): [0, 8) the one-kernel form's band-queue counters, [16, 112) the profiling build's phase
+ * sums, [112, 116) the dense counters, [200, 206) the three lists' cursors / counts */
+#define SVT_HIP_ME_LIST_CURSOR(l) (200 + 2 * (l))
+#define SVT_HIP_ME_LIST_COUNT(l) (201 + 2 * (l))
+#define SVT_HIP_ME_QUEUE_BLOCK_BYTES 2048
+#ifndef SVT_HIP_ME_MID_WAVES_PER_SIMD
+#define SVT_HIP_ME_MID_WAVES_PER_SIMD 4
+#endif
+#ifndef SVT_HIP_ME_SEARCH_WAVES_PER_SIMD
+#define SVT_HIP_ME_SEARCH_WAVES_PER_SIMD 4
+#endif
+#ifndef SVT_HIP_ME_TAIL_WAVES_PER_SIMD
+#define SVT_HIP_ME_TAIL_WAVES_PER_SIMD 2
+#endif
+
 struct MeBatchHeader {
     uint32_t  n_pictures, n_slot; // n_slot: the largest number of (list, reference) pairs a picture of the launch searches
     uint32_t  job_base[SVT_HIP_ME_MAX_PICTURES + 1];
@@ -139,6 +159,11 @@ struct MeBatchHeader {
     uint32_t *queue_head; // SVT_HIP_ME_QUEUES counters, zeroed before launch
     MeDenseSlot *dense;   // results of the dense pre-pass, [job_base[n_pictures]][n_slot][SVT_HIP_ME_DENSE_KINDS]; null: no pre-pass
     uint32_t  n_dense_entries, n_dense_units;
+    // staged launches (null otherwise): per job SVT_HIP_ME_STAGE_BYTES of travelling state, a flag word; three job lists (0: deferred to the
+    // whole-pipeline kernel, 1 / 2: level-1 / level-2 searches in the staged form)
+    uint8_t   *stage;
+    uint32_t  *job_flags;
+    uint32_t  *lists[3];
 };
 #ifdef __cplusplus
 static_assert(sizeof(MeBatchHeader) <= SVT_HIP_ME_HEADER_BYTES, "header size");

@@ -156,16 +156,33 @@ struct St { // per-block state (subset of MeContext, me_context.h:366-509)
 // arena.  When every picture of the launch sub-samples both the HME and the integer search (SUB_SAD_SEARCH: every other row),
 // the source views keep their even rows only (cshift = 1): row r of a view lives at row r >> cshift.
 struct LdsLayout { uint32_t src16, src32, src64, bsad, bmv, dense, win, total; };
-__host__ __device__ constexpr LdsLayout lds_layout(int n_slot, int cshift, int dense = 1) {
+// Kernel modes.  kMeFull: the whole per-block pipeline in one wave (svt_hip_me_b64_kernel).  The STAGED form (launches with a dense pre-pass)
+// cuts the same pipeline at its searches into small kernels -- each with the register / LDS budget of its own part, hence many more blocks in
+// flight per CU than the one-wave-does-everything form, whose time goes into the latencies of a long dependent chain:
+//   kMeMid1  zero-MV SADs, pre-HME / level-0 results from the pre-pass, level-1 requests     (control only)
+//   kMeS1    the level-1 searches of every block (direct form)      kMeS1f  the same for the blocks whose searches need the staged form
+//   kMeMid2  level-1 results -> level-2 requests                    (control only)
+//   kMeS2 / kMeS2f  the level-2 searches
+//   kMeTail  level-2 results, search centres, check-00, probe, integer search, pruning, candidates, outputs
+// A block's state (the head of St) and its search requests / results travel through HBM between them.
+constexpr int kMeFull = 0, kMeMid1 = 1, kMeS1 = 2, kMeS1f = 3, kMeMid2 = 4, kMeS2 = 5, kMeS2f = 6, kMeTail = 7;
+constexpr uint32_t kStagedMinJobs = 4096; // blocks of a launch from which the staged form is used
+__host__ __device__ constexpr bool me_is_search(int m) { return m == kMeS1 || m == kMeS1f || m == kMeS2 || m == kMeS2f; }
+__host__ __device__ constexpr bool me_is_staged_search(int m) { return m == kMeS1f || m == kMeS2f; }
+constexpr int kDirectWinBytes = 5120; // the direct searches' arena: a step's 64 x 5 window pieces, then the per-position sums [kMaxReq][kNarrowMaxPos] u32
+__host__ __device__ constexpr LdsLayout lds_layout(int n_slot, int cshift, int dense = 1, int mode = 0) {
+    const bool v16 = mode == kMeFull, v32 = mode == kMeFull || mode == kMeS1 || mode == kMeS1f, v64 = mode == kMeFull || mode == kMeS2 || mode == kMeS2f || mode == kMeTail;
+    const bool best = mode == kMeFull || mode == kMeTail, slots = dense && (mode == kMeFull || mode == kMeMid1);
+    const uint32_t arena = (mode == kMeMid1 || mode == kMeMid2) ? 0u : (mode == kMeS1 || mode == kMeS2) ? (uint32_t)kDirectWinBytes : (uint32_t)kWinBytes;
     LdsLayout l = {};
     l.src16 = (uint32_t)((sizeof(St) + 15) & ~(size_t)15);
-    l.src32 = l.src16 + (uint32_t)((16 >> cshift) * kSrc16Pitch);
-    l.src64 = l.src32 + (uint32_t)((32 >> cshift) * kSrc32Pitch);
-    l.bsad  = l.src64 + (uint32_t)((64 >> cshift) * kSrc64Pitch);
-    l.bmv   = l.bsad + (uint32_t)n_slot * 85 * 4;
-    l.dense = (l.bmv + (uint32_t)n_slot * 85 * 4 + 15) & ~15u; // the block's slots of the dense pre-pass: n_slot x SVT_HIP_ME_DENSE_KINDS x 16 bytes
-    l.win   = l.dense + (dense ? (uint32_t)n_slot * SVT_HIP_ME_DENSE_KINDS * 16u : 0u);
-    l.total = l.win + (uint32_t)kWinBytes;
+    l.src32 = l.src16 + (v16 ? (uint32_t)((16 >> cshift) * kSrc16Pitch) : 0u);
+    l.src64 = l.src32 + (v32 ? (uint32_t)((32 >> cshift) * kSrc32Pitch) : 0u);
+    l.bsad  = l.src64 + (v64 ? (uint32_t)((64 >> cshift) * kSrc64Pitch) : 0u);
+    l.bmv   = l.bsad + (best ? (uint32_t)n_slot * 85 * 4 : 0u);
+    l.dense = (l.bmv + (best ? (uint32_t)n_slot * 85 * 4 : 0u) + 15) & ~15u; // the block's slots of the dense pre-pass: n_slot x SVT_HIP_ME_DENSE_KINDS x 16 bytes
+    l.win   = l.dense + (slots ? (uint32_t)n_slot * SVT_HIP_ME_DENSE_KINDS * 16u : 0u);
+    l.total = l.win + arena;
     return l;
 }
 extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[]; // the wave's LDS slice
@@ -712,23 +729,43 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
 // rows, and a lane fetches its window rows straight from global memory (a row is NDW + 2 dwords: two or five unaligned 16-byte loads, the
 // next row on its way while the current one is evaluated) -- no tile plan, no staging rounds, one pass for the whole stage.  Per-position
 // sums meet in the (idle) arena by LDS atomics; one arg-min per search.  Returns false (nothing done) when the stage does not qualify.
+// One pass of a direct stage.  A lane owns one item (an octet of positions x a slice of block rows) and needs, per block row, the NDW + 2
+// window dwords under it: NV 16-byte pieces of ONE window row.  Fetched by their owner the pieces of a step lie in 64 different rows -- every
+// lane of every load instruction in a cache line of its own, and the texture addresser, which takes them one line at a time, becomes the
+// stage's bound (measured: TA busy 85 % of the level-2 kernel's time).  So the wave fetches a step's 64 x NV pieces in LINEAR order instead
+// (piece n = owner n / NV, part n % NV: the NV lanes of a row side by side in one or two lines), hands them over through the arena, and
+// every owner reads its row back with NV ds_read_b128 (lane stride NV x 16 bytes, NV odd: conflict-free).  The next step's pieces are on
+// their way while the current one is evaluated.  `wp` = the owner's first window row (idle lanes: rows <= 0), `wstep` uniform.
 template <int NDW>
-__device__ __forceinline__ void direct_rows(const uint8_t *src, int sp, int srs, const uint8_t *wp, long long wstep, int e0, int e1, uint32_t out[8]) {
+__device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, int sp, int srs, const uint8_t *wp, long long wstep, int e0, int rows, int rows_max, uint32_t out[8]) {
     constexpr int NV = (NDW + 2 + 3) / 4, kRowsPerFlush = 64 / NDW;
+    static_assert(NV & 1, "owners read their pieces back without bank conflicts");
+    const int lane = threadIdx.x;
+    const uint8_t *pp[NV]; // where this lane fetches piece (lane + 64 k) of a step
+    int            pn[NV]; // steps its owner makes
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int n = lane + 64 * k, owner = n / NV, part = n - owner * NV;
+        const u64 base = ((u64)(uint32_t)__shfl((int)(uint32_t)((uintptr_t)wp >> 32), owner, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)(uintptr_t)wp, owner, 64);
+        pp[k] = reinterpret_cast<const uint8_t *>((uintptr_t)base) + 16 * part;
+        pn[k] = __shfl(rows, owner, 64);
+    }
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    V4U cur[NV], nxt[NV];
+    V4U v[NV];
 #pragma unroll
-    for (int k = 0; k < NV; k++) cur[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(wp) + 16 * k);
-    for (int eb = e0; eb < e1; eb += kRowsPerFlush) {
-        const int ee = eb + kRowsPerFlush < e1 ? eb + kRowsPerFlush : e1;
-        u64       acc0 = 0, acc1 = 0;
-        for (int e = eb; e < ee; e++) {
-            wp += wstep;
-            if (e + 1 < e1) { // the next row is on its way while this one is evaluated
+    for (int k = 0; k < NV; k++) v[k] = pn[k] > 0 ? *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k])) : V4U{0, 0, 0, 0};
+    u64 acc0 = 0, acc1 = 0;
+    for (int t = 0; t < rows_max; t++) { // uniform
 #pragma unroll
-                for (int k = 0; k < NV; k++) nxt[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(wp) + 16 * k);
-            }
-            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + e * srs * sp);
+        for (int k = 0; k < NV; k++) *reinterpret_cast<V4U *>(arena + 16 * (lane + 64 * k)) = v[k];
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            pp[k] += wstep;
+            if (t + 1 < pn[k]) v[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k]));
+        }
+        if (t < rows) {
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (e0 + t) * srs * sp);
             uint32_t sv[NDW], wv[4 * NV];
 #pragma unroll
             for (int j = 0; j < NDW; j += 4) {
@@ -736,56 +773,76 @@ __device__ __forceinline__ void direct_rows(const uint8_t *src, int sp, int srs,
                 sv[j] = q.x; sv[j + 1] = q.y; sv[j + 2] = q.z; sv[j + 3] = q.w;
             }
 #pragma unroll
-            for (int k = 0; k < NV; k++) { wv[4 * k] = cur[k].x; wv[4 * k + 1] = cur[k].y; wv[4 * k + 2] = cur[k].z; wv[4 * k + 3] = cur[k].w; }
+            for (int k = 0; k < NV; k++) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(arena + 16 * (lane * NV + k));
+                wv[4 * k] = q.x; wv[4 * k + 1] = q.y; wv[4 * k + 2] = q.z; wv[4 * k + 3] = q.w;
+            }
 #pragma unroll
             for (int j = 0; j < NDW; j++) {
                 acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 1] << 32) | wv[j], sv[j], acc0);
                 acc1 = __builtin_amdgcn_qsad_pk_u16_u8(((u64)wv[j + 2] << 32) | wv[j + 1], sv[j], acc1);
             }
-#pragma unroll
-            for (int k = 0; k < NV; k++) cur[k] = nxt[k];
         }
+        if ((t + 1) % kRowsPerFlush == 0 || t + 1 == rows_max) { // uniform: the 16-bit sums hold kRowsPerFlush rows
 #pragma unroll
-        for (int i = 0; i < 4; i++) { a[i] += (uint32_t)((acc0 >> (16 * i)) & 0xFFFF); a[4 + i] += (uint32_t)((acc1 >> (16 * i)) & 0xFFFF); }
+            for (int i = 0; i < 4; i++) { a[i] += (uint32_t)((acc0 >> (16 * i)) & 0xFFFF); a[4 + i] += (uint32_t)((acc1 >> (16 * i)) & 0xFFFF); }
+            acc0 = acc1 = 0;
+        }
+        wave_sync(); // the arena is rewritten
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = a[i];
 }
 
+// do the stage's requests st.req[0 .. nreq) qualify for run_small_searches_direct?  (wave-uniform answer)
+__device__ __forceinline__ bool small_direct_ok(const St &st) {
+    const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
+    const Req &r0 = st.req[0];
+    const int  w = (int16_t)uni((uint32_t)r0.sa_w), h = (int16_t)uni((uint32_t)r0.sa_h), bw = (int)uni(r0.bw), bh = (int)uni(r0.bh), rs = (int)uni(r0.rs),
+               level = (int)uni(r0.level), stride = (int)uni((uint32_t)r0.stride);
+    bool ok = true;
+    if (lane < nreq) {
+        const Req &r = st.req[lane];
+        ok = r.sa_w == w && r.sa_h == h && r.bw == bw && r.bh == bh && r.rs == rs && r.level == level && (int)r.stride == stride && !r.skip_even && !r.done;
+    }
+    if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
+    return ((w + 7) >> 3) * h * nreq <= kThreads; // octet items of one slice
+}
 __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
     St       &st   = sh.st;
     const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
     // every search like the first one, few positions, whole-vector source rows
+    if (!small_direct_ok(st)) return false;
     const Req &r0 = st.req[0];
     const int  w = (int16_t)uni((uint32_t)r0.sa_w), h = (int16_t)uni((uint32_t)r0.sa_h), bw = (int)uni(r0.bw), bh = (int)uni(r0.bh), rs = (int)uni(r0.rs),
                level = (int)uni(r0.level);
-    bool ok = true;
-    if (lane < nreq) {
-        const Req &r = st.req[lane];
-        ok = r.sa_w == w && r.sa_h == h && r.bw == bw && r.bh == bh && r.rs == rs && r.level == level && !r.skip_even && !r.done;
-    }
-    if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
     const int ng = (w + 7) >> 3, per = ng * h, Q = per * nreq; // octet items of one slice
-    if (Q > kThreads) return false;
     int       S        = imin(bh, (int)uni(div_by_rcp((uint32_t)kThreads, rcp_of((uint32_t)Q))));
     const int rows_per = (int)uni(div_by_rcp((uint32_t)(bh + S - 1), rcp_of((uint32_t)S)));
     S                  = (int)uni(div_by_rcp((uint32_t)(bh + rows_per - 1), rcp_of((uint32_t)rows_per)));
-    uint32_t *sad = reinterpret_cast<uint32_t *>(LDS(sh.win)); // [nreq][kNarrowMaxPos]
-    for (int p = lane; p < nreq * kNarrowMaxPos; p += kThreads) sad[p] = 0;
-    wave_sync();
+    uint32_t *sad = reinterpret_cast<uint32_t *>(LDS(sh.win)); // [nreq][kNarrowMaxPos], once the rows have passed through the arena
     const uint8_t *src = src_view(sh, level);
     const int      sp  = (level == 2) ? kSrc64Pitch : (level == 1 ? kSrc32Pitch : kSrc16Pitch), srs = rs >> sh.cshift;
-    if (lane < Q * S) {
+    const long long wstep = (long long)rs * (long long)(int)uni((uint32_t)r0.stride);
+    const bool mine = lane < Q * S;
+    int req = 0, y = 0, g = 0, e0 = 0, rows = 0;
+    const uint8_t *wp = nullptr;
+    if (mine) {
         const int slice = (int)div_by_rcp((uint32_t)lane, rcp_of((uint32_t)Q)), q = lane - slice * Q;
-        const int req = (int)div_by_rcp((uint32_t)q, rcp_of((uint32_t)per)), ql = q - req * per;
-        const int y = (int)div_by_rcp((uint32_t)ql, rcp_of((uint32_t)ng)), g = ql - y * ng;
+        req = (int)div_by_rcp((uint32_t)q, rcp_of((uint32_t)per));
+        const int ql = q - req * per;
+        y = (int)div_by_rcp((uint32_t)ql, rcp_of((uint32_t)ng)); g = ql - y * ng;
         const Req &r = st.req[req];
-        const long long wstep = (long long)rs * (long long)r.stride;
-        const int e0 = slice * rows_per, e1 = imin(e0 + rows_per, bh);
-        const uint8_t *wp = r.win + (long long)y * r.stride + (long long)e0 * wstep + 8 * g;
-        uint32_t s8[8];
-        if (bw == 64) direct_rows<16>(src, sp, srs, wp, wstep, e0, e1, s8);
-        else direct_rows<8>(src, sp, srs, wp, wstep, e0, e1, s8);
+        e0   = slice * rows_per;
+        rows = imin(e0 + rows_per, bh) - e0;
+        wp   = r.win + (long long)y * r.stride + (long long)e0 * wstep + 8 * g;
+    }
+    uint32_t s8[8];
+    if (bw == 64) direct_rows<16>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    else direct_rows<8>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    for (int p = lane; p < nreq * kNarrowMaxPos; p += kThreads) sad[p] = 0;
+    wave_sync();
+    if (mine) {
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if (8 * g + i < w) atomicAdd(&sad[req * kNarrowMaxPos + y * w + 8 * g + i], s8[i]);
@@ -1154,8 +1211,10 @@ __device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy, 
 #endif
 #define CTRL_PRIO(x) __builtin_amdgcn_s_setprio(x)
 
-extern "C" __global__ void __launch_bounds__(64, SVT_HIP_ME_WAVES_PER_SIMD)
-svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams) {
+// `launch_flags` bit 0: jobs come from a list (kMeFull: the deferred blocks of a staged launch; kMeS1f / kMeS2f always do).
+constexpr size_t kPersistBytes = (offsetof(St, req) + 15) & ~(size_t)15; // the head of St that travels between the kernels of a staged launch
+template <int MODE>
+__device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams, const uint32_t launch_flags) {
     St     &st = *reinterpret_cast<St *>(g_lds);
     // launch parameters: read-only, uniform addresses -> scalar loads through the constant cache, values in SGPRs
     typedef const SVT_CONST_AS MeBatchHeader CHeader;
@@ -1164,7 +1223,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
     // MeContext.p_sb_best_sad / p_sb_best_mv rows of the (list, reference) pairs in use, behind the fixed part of the LDS slice
     const int       cshift = (int)hdr.cshift;
     const bool      has_dense = hdr.dense != nullptr; // uniform
-    const LdsLayout lay    = lds_layout((int)hdr.n_slot, cshift, has_dense ? 1 : 0);
+    const LdsLayout lay    = lds_layout((int)hdr.n_slot, cshift, has_dense ? 1 : 0, MODE);
     uint32_t *const bsad = reinterpret_cast<uint32_t *>(g_lds + lay.bsad);
     uint32_t *const bmv  = reinterpret_cast<uint32_t *>(g_lds + lay.bmv);
     const MeDenseSlot *const dense_lds = has_dense ? reinterpret_cast<const MeDenseSlot *>(g_lds + lay.dense) : nullptr;
@@ -1176,8 +1235,42 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7;
     int queue_probe = 0; // only lane 0's copy is used
+    // every kernel of a staged launch drains the same ranges with counters of its own; the list kernels walk a list filled by an earlier kernel
+    // The one-kernel form balances its long, uneven blocks through the band queues (a returning device-scope atomic per block: nothing next to
+    // ~100 us of work).  The short kernels of a staged launch cannot afford one per job -- measured: ~0.1 us per wave and kernel, every one of
+    // them serialised at the memory side -- so their waves take a contiguous share of the job range instead (neighbouring blocks, whose windows
+    // overlap, still follow each other on one CU); only the few waves of the list kernels pull their (rare) jobs with an atomic.
+    constexpr int kList = MODE == kMeS1f ? 1 : MODE == kMeS2f ? 2 : 0; // which list a list-mode launch of this kernel walks
+    const bool list_mode = (launch_flags & 1u) || me_is_staged_search(MODE);
+    const uint32_t n_total = hdr.job_base[hdr.n_pictures];
+    // Wave i of a staged kernel walks band (i % 8) of the launch -- the band its XCD would pull from in the one-kernel form, workgroups being dealt
+    // round-robin over the XCDs -- with the band's other waves, interleaved: what the chip works on at one time is a run of neighbouring blocks,
+    // whose windows overlap in that XCD's L2.
+    uint32_t share_next = 0, share_end = 0, share_step = 1;
+    if (MODE != kMeFull && !list_mode) {
+        if (gridDim.x >= SVT_HIP_ME_QUEUES) {
+            const uint32_t q = blockIdx.x % SVT_HIP_ME_QUEUES;
+            share_step = (gridDim.x - q + SVT_HIP_ME_QUEUES - 1) / SVT_HIP_ME_QUEUES;
+            share_next = hdr.queue_begin[q] + blockIdx.x / SVT_HIP_ME_QUEUES;
+            share_end  = hdr.queue_begin[q + 1];
+        } else {
+            share_step = gridDim.x; share_next = blockIdx.x; share_end = n_total;
+        }
+    }
     auto fetch_job = [&]() {
         int job = -1;
+        if (list_mode) {
+            // (a look before the pull: the lists are empty or short, and a returning atomic per idle wave on one word is ~0.1 us each, in series)
+            const uint32_t n = __hip_atomic_load(&hdr.queue_head[SVT_HIP_ME_LIST_COUNT(kList)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_load(&hdr.queue_head[SVT_HIP_ME_LIST_CURSOR(kList)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n) return job;
+            const uint32_t k = atomicAdd(&hdr.queue_head[SVT_HIP_ME_LIST_CURSOR(kList)], 1u);
+            if (k < n) job = (int)hdr.lists[kList][k];
+            return job;
+        }
+        if (MODE != kMeFull) {
+            if (share_next < share_end) { job = (int)share_next; share_next += share_step; }
+            return job;
+        }
         while (queue_probe < SVT_HIP_ME_QUEUES) {
             const int      q  = (int)((xcc + queue_probe) & 7);
             const uint32_t lo = hdr.queue_begin[q], hi = hdr.queue_begin[q + 1];
@@ -1189,6 +1282,31 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         }
         return job;
     };
+    // a block's travelling state and requests (staged launches)
+    auto stage_base = [&](int gjob) { return hdr.stage + (size_t)gjob * SVT_HIP_ME_STAGE_BYTES; };
+    auto export_state = [&](int gjob) {
+        uint4 *dst = reinterpret_cast<uint4 *>(stage_base(gjob));
+        const uint4 *src = reinterpret_cast<const uint4 *>(g_lds);
+        for (int i = tid; i < (int)(kPersistBytes / 16); i += kThreads) dst[i] = src[i];
+    };
+    auto import_state = [&](int gjob) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(stage_base(gjob));
+        uint4 *dst = reinterpret_cast<uint4 *>(g_lds);
+        for (int i = tid; i < (int)(kPersistBytes / 16); i += kThreads) dst[i] = src[i];
+    };
+    static_assert(kPersistBytes + kMaxReq * (sizeof(Req) + sizeof(u64)) <= SVT_HIP_ME_STAGE_BYTES, "a block's record holds its state, its requests and their results");
+    auto export_reqs = [&](int gjob) { // st.req[0 .. nreq) (nreq travels with the state)
+        uint4 *dst = reinterpret_cast<uint4 *>(stage_base(gjob) + kPersistBytes);
+        const uint4 *src = reinterpret_cast<const uint4 *>(st.req);
+        static_assert(sizeof(Req) == 24 && (kMaxReq * sizeof(Req)) % 16 == 0, "requests are copied as 16-byte words");
+        for (int i = tid; i < (int)(kMaxReq * sizeof(Req) / 16); i += kThreads) dst[i] = src[i];
+    };
+    auto import_reqs = [&](int gjob) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(stage_base(gjob) + kPersistBytes);
+        uint4 *dst = reinterpret_cast<uint4 *>(st.req);
+        for (int i = tid; i < (int)(kMaxReq * sizeof(Req) / 16); i += kThreads) dst[i] = src[i];
+    };
+    auto keys_of = [&](int gjob) { return reinterpret_cast<u64 *>(stage_base(gjob) + kPersistBytes + kMaxReq * sizeof(Req)); };
     PROF_DECL;
 
     for (;;) {
@@ -1215,6 +1333,43 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
 #define BEST_SAD(li, ri) (bsad + (((li) ? r0n : 0) + (ri)) * 85)
 #define BEST_MV(li, ri) (bmv + (((li) ? r0n : 0) + (ri)) * 85)
         const int n_rows   = r0n + (nl > 1 ? d.num_of_ref_pic_to_search[1] : 0);
+        uint32_t *const jflag = hdr.job_flags ? hdr.job_flags + gjob : nullptr; // staged launches: how the block travels
+        if constexpr (MODE != kMeFull && MODE != kMeMid1) {
+            const uint32_t f = __hip_atomic_load(jflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f & SVT_HIP_ME_JOB_DEFERRED) continue; // uniform: the whole-pipeline kernel makes this block at the end of the launch
+            if constexpr (MODE == kMeS1) { if (f & SVT_HIP_ME_JOB_STAGED1) continue; } // its level-1 searches take the staged form (kMeS1f)
+            if constexpr (MODE == kMeS2) { if (f & SVT_HIP_ME_JOB_STAGED2) continue; }
+        }
+        if constexpr (me_is_search(MODE)) {
+            // ---- search-only kernels: the block's requests in, their keys out ------------------------------------------------
+            constexpr int lvl = (MODE == kMeS1 || MODE == kMeS1f) ? 1 : 2;
+            const int ox = (int)(bxi * 64), oy = (int)(byi * 64), rstep = 1 << cshift;
+            import_reqs(gjob);
+            if (tid == 0) st.nreq = *reinterpret_cast<const int *>(stage_base(gjob) + offsetof(St, nreq));
+            if constexpr (lvl == 1) {
+                for (int i = tid; i < (32 >> cshift) * 2; i += kThreads) {
+                    const int row = i >> 1, cc = i & 1;
+                    uint4 v; memcpy(&v, plane_at(p.cur.lvl[1], (ox >> 1) + cc * 16, (oy >> 1) + row * rstep), 16);
+                    *reinterpret_cast<uint4 *>(&LDS(sh.src32)[row * kSrc32Pitch + cc * 16]) = v;
+                }
+            } else {
+                for (int i = tid; i < (64 >> cshift) * 4; i += kThreads) {
+                    const int row = i >> 2, cc = i & 3;
+                    uint4 v; memcpy(&v, plane_at(p.cur.lvl[2], ox + cc * 16, oy + row * rstep), 16);
+                    *reinterpret_cast<uint4 *>(&LDS(sh.src64)[row * kSrc64Pitch + cc * 16]) = v;
+                }
+            }
+            wave_sync();
+            if (st.nreq) { // uniform
+                if constexpr (me_is_staged_search(MODE)) run_searches(sh PROF_ARG);
+                else (void)run_small_searches_direct(sh PROF_ARG); // (the Mid kernel routed the block here because it qualifies)
+            }
+            wave_sync();
+            u64 *keys = keys_of(gjob);
+            if (tid < kMaxReq) keys[tid] = st.req_key[tid];
+            wave_sync();
+            continue;
+        }
 
         // ---- block setup (me_process.c:183-214; motion_estimation.c:3090-3105, init_me_hme_data :3010-3071) ---
         if (tid == 0) {
@@ -1227,7 +1382,8 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             st.nreq = 0; st.nme = 0; st.nprobe = 0;
         }
         for (int i = tid; i < 3 * 2 * 4 * 2 * 2; i += kThreads) { (&st.hx[0][0][0][0][0])[i] = 0; (&st.hy[0][0][0][0][0])[i] = 0; (&st.hs[0][0][0][0][0])[i] = 0; }
-        for (int i = tid; i < n_rows * 85; i += kThreads) { bmv[i] = 0; bsad[i] = SVT_HIP_MAX_SAD_VALUE; }
+        if constexpr (MODE == kMeFull || MODE == kMeTail)
+            for (int i = tid; i < n_rows * 85; i += kThreads) { bmv[i] = 0; bsad[i] = SVT_HIP_MAX_SAD_VALUE; }
         if (tid < 8) {
             const int li = tid >> 2, ri = tid & 3;
             st.do_ref[li][ri] = 1; st.hme_sad64[li][ri] = 0xFFFFFFFFull; st.sr_divisor[li][ri] = 1; st.zz_sad[li][ri] = ~0u;
@@ -1238,21 +1394,22 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                 st.performed_phme[li][ri][sri] = 0;
             }
         }
-        if (has_dense && tid < n_rows * kDenseKinds) // this block's slots of the dense pre-pass (read by the pre-HME / level-0 stages)
+        if ((MODE == kMeFull || MODE == kMeMid1) && has_dense && tid < n_rows * kDenseKinds) // this block's slots of the dense pre-pass (read by the pre-HME / level-0 stages)
             reinterpret_cast<uint4 *>(g_lds + lay.dense)[tid] = reinterpret_cast<const uint4 *>(hdr.dense)[((size_t)gjob * hdr.n_slot) * kDenseKinds + tid];
         // init_zz_sad (motion_estimation.c:2382-2437) rides on the set-up: while a lane holds a 16-byte piece of the source block it fetches the
         // same piece of every searched reference and adds up the zero-MV SAD of the even rows (get_zz_sad, :1667-1689) -- no staging, no
         // search rounds for single positions.  Sums in zz_sum[k], k = the searched (list, reference) pairs in the reference's loop order.
-        const bool zz_on = c.me_early_exit_th || c.me_safe_limit_zz_th; // uniform
+        const bool zz_on = (MODE == kMeFull || MODE == kMeMid1) && (c.me_early_exit_th || c.me_safe_limit_zz_th); // uniform
         const int  nzz   = zz_on ? r0n + ((nl > 1 && d.temporal_layer_index > 0) ? d.num_of_ref_pic_to_search[1] : 0) : 0;
         uint32_t   zz_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         { // source views -> LDS (every row, or the even rows only: cshift)
             const int ox = (int)(bxi * 64), oy = (int)(byi * 64), rstep = 1 << cshift;
             const int bw64 = imin(64, (int)d.aligned_width - ox), bh64 = imin(64, (int)d.aligned_height - oy);
+            if constexpr (MODE != kMeMid2)
             for (int i = tid; i < (64 >> cshift) * 4; i += kThreads) {
                 const int row = i >> 2, cc = i & 3;
                 uint4 v; memcpy(&v, plane_at(p.cur.lvl[2], ox + cc * 16, oy + row * rstep), 16);
-                *reinterpret_cast<uint4 *>(&LDS(sh.src64)[row * kSrc64Pitch + cc * 16]) = v;
+                if constexpr (MODE != kMeMid1) *reinterpret_cast<uint4 *>(&LDS(sh.src64)[row * kSrc64Pitch + cc * 16]) = v;
                 const int y = row * rstep, x = cc * 16;
                 if (nzz && !(y & 1) && y < bh64 && x < bw64) { // block widths are multiples of 8: a piece is whole or half inside
                     const bool whole = x + 8 < bw64;
@@ -1268,14 +1425,16 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
                         }
                 }
             }
-            for (int i = tid; i < (32 >> cshift) * 2; i += kThreads) {
-                const int row = i >> 1, cc = i & 1;
-                uint4 v; memcpy(&v, plane_at(p.cur.lvl[1], (ox >> 1) + cc * 16, (oy >> 1) + row * rstep), 16);
-                *reinterpret_cast<uint4 *>(&LDS(sh.src32)[row * kSrc32Pitch + cc * 16]) = v;
-            }
-            for (int i = tid; i < (16 >> cshift); i += kThreads) {
-                uint4 v; memcpy(&v, plane_at(p.cur.lvl[0], ox >> 2, (oy >> 2) + i * rstep), 16);
-                *reinterpret_cast<uint4 *>(&LDS(sh.src16)[i * kSrc16Pitch]) = v;
+            if constexpr (MODE == kMeFull) {
+                for (int i = tid; i < (32 >> cshift) * 2; i += kThreads) {
+                    const int row = i >> 1, cc = i & 1;
+                    uint4 v; memcpy(&v, plane_at(p.cur.lvl[1], (ox >> 1) + cc * 16, (oy >> 1) + row * rstep), 16);
+                    *reinterpret_cast<uint4 *>(&LDS(sh.src32)[row * kSrc32Pitch + cc * 16]) = v;
+                }
+                for (int i = tid; i < (16 >> cshift); i += kThreads) {
+                    uint4 v; memcpy(&v, plane_at(p.cur.lvl[0], ox >> 2, (oy >> 2) + i * rstep), 16);
+                    *reinterpret_cast<uint4 *>(&LDS(sh.src16)[i * kSrc16Pitch]) = v;
+                }
             }
         }
 #pragma unroll
@@ -1286,6 +1445,12 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
             }
         wave_sync();
 
+        if constexpr (MODE == kMeMid2 || MODE == kMeTail) { // the block's state as the previous kernel left it, and the keys of the searches made in between
+            import_state(gjob);
+            const u64 *keys = keys_of(gjob);
+            if (tid < kMaxReq) st.req_key[tid] = keys[tid];
+            wave_sync();
+        }
         PROF(1);
         // The stages below run as one loop around a SINGLE inlined copy of run_searches / run_me_searches (the kernel
         // must stay small enough for the instruction cache shared by two CUs): each stage has a "pre" part that
@@ -1691,7 +1856,64 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         if (SVT_ME_ABLATE == 1) continue;
 #endif
         const int n_prehme = c.prehme_l1_early_exit ? nl : 1, n_l0 = l0_dep ? 2 : 1, n_group = me_dep ? 2 : 1;
-        int step = kZz, bi = 0; // uniform: derived from launch parameters only
+        if constexpr (MODE == kMeMid1 || MODE == kMeMid2) {
+            // The control-only kernels of a staged launch: the one-kernel form's stage loop, written out for the stages they own (same
+            // order, same barriers).  A pre-HME / level-0 search the pre-pass did not make defers the block to the whole-pipeline kernel.
+            const bool hme_on = c.enable_hme_flag;
+            bool defer = false;
+            uint32_t flags = 0;
+            if constexpr (MODE == kMeMid1) {
+                auto pending = [&]() { return __any(tid < st.nreq && !st.req[tid].done); };
+                if (c.me_early_exit_th || c.me_safe_limit_zz_th) { zz_pre(); wave_sync(); zz_post(); wave_sync(); }
+                if (c.prehme_enable) {
+                    for (int b2 = 0; b2 < n_prehme; b2++) {
+                        prehme_pre(b2); wave_sync();
+                        if (pending()) { defer = true; break; }
+                        prehme_post(b2);
+                        if (b2 + 1 < n_prehme) wave_sync();
+                    }
+                    if (!defer) { prehme_final(); wave_sync(); }
+                }
+                if (!defer && hme_on && c.enable_hme_level0_flag)
+                    for (int b2 = 0; b2 < n_l0; b2++) {
+                        l0_pre(b2); wave_sync();
+                        if (pending()) { defer = true; break; }
+                        l0_post(b2); wave_sync();
+                    }
+                if (!defer) {
+                    if (hme_on && c.enable_hme_level1_flag) lvl_pre(1);
+                    else if (tid == 0) st.nreq = 0;
+                    wave_sync();
+                }
+            } else {
+                flags = __hip_atomic_load(jflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (hme_on && c.enable_hme_level1_flag) { lvl_post(1); wave_sync(); }
+                if (hme_on && c.enable_hme_level2_flag) lvl_pre(2);
+                else if (tid == 0) st.nreq = 0;
+                wave_sync();
+            }
+            if (defer) {
+                if (tid == 0) {
+                    *jflag = SVT_HIP_ME_JOB_DEFERRED;
+                    hdr.lists[0][atomicAdd(&hdr.queue_head[SVT_HIP_ME_LIST_COUNT(0)], 1u)] = (uint32_t)gjob;
+                }
+            } else {
+                constexpr int kL = MODE == kMeMid1 ? 1 : 2; // the list of blocks whose searches of the coming level need the staged form
+                const bool staged = st.nreq && !small_direct_ok(st); // (uniform)
+                export_state(gjob);
+                export_reqs(gjob);
+                if (tid == 0) {
+                    *jflag = flags | (staged ? (kL == 1 ? SVT_HIP_ME_JOB_STAGED1 : SVT_HIP_ME_JOB_STAGED2) : 0u);
+                    if (staged) hdr.lists[kL][atomicAdd(&hdr.queue_head[SVT_HIP_ME_LIST_COUNT(kL)], 1u)] = (uint32_t)gjob;
+                }
+            }
+            wave_sync();
+            continue;
+        }
+        if constexpr (MODE == kMeTail) {
+            if (c.enable_hme_flag && c.enable_hme_level2_flag) { lvl_post(2); wave_sync(); }
+        }
+        int step = MODE == kMeTail ? kC00 : kZz, bi = 0; // uniform: derived from launch parameters only
         PROF(2);
         while (step != kEnd) {
             bool run = true;
@@ -1981,7 +2203,7 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
         PROF(16);
     }
     PROF_FLUSH(hdr.queue_head + 16);
-    if (has_dense) { // counters of the context's diagnostics entry (svt_hip_me_dense_counters)
+    if ((MODE == kMeFull || MODE == kMeMid1) && has_dense) { // counters of the context's diagnostics entry (svt_hip_me_dense_counters)
         const uint32_t h = wave_sum_u32(n_hit), m = wave_sum_u32(n_miss);
         if (tid == 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(hdr.queue_head + SVT_HIP_ME_COUNTER_WORD), (unsigned long long)h);
@@ -1992,6 +2214,21 @@ svt_hip_me_b64_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelPara
 
 #undef BEST_SAD
 #undef BEST_MV
+
+#define SVT_ME_KERNEL(NAME, MODE, WAVES)                                                                                                              \
+    extern "C" __global__ void __launch_bounds__(64, WAVES) NAME(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams,   \
+                                                                 const uint32_t launch_flags) {                                                       \
+        me_b64_body<MODE>(ghdr, gparams, launch_flags);                                                                                               \
+    }
+SVT_ME_KERNEL(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD)
+SVT_ME_KERNEL(svt_hip_me_mid1_kernel, kMeMid1, SVT_HIP_ME_MID_WAVES_PER_SIMD)
+SVT_ME_KERNEL(svt_hip_me_s1_kernel, kMeS1, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD)
+SVT_ME_KERNEL(svt_hip_me_s1f_kernel, kMeS1f, SVT_HIP_ME_WAVES_PER_SIMD)
+SVT_ME_KERNEL(svt_hip_me_mid2_kernel, kMeMid2, SVT_HIP_ME_MID_WAVES_PER_SIMD)
+SVT_ME_KERNEL(svt_hip_me_s2_kernel, kMeS2, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD)
+SVT_ME_KERNEL(svt_hip_me_s2f_kernel, kMeS2f, SVT_HIP_ME_WAVES_PER_SIMD)
+SVT_ME_KERNEL(svt_hip_me_tail_kernel, kMeTail, SVT_HIP_ME_TAIL_WAVES_PER_SIMD)
+#undef SVT_ME_KERNEL
 
 #include "me_dense.inl"
 
@@ -2027,34 +2264,43 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     static thread_local MeDenseEntry entries[SVT_HIP_ME_DENSE_MAX_ENTRIES];
     uint32_t n_entries = 0, n_units = 0;
     if (ctx->me_dense) n_entries = dense_plan(params, n_jobs, n_pictures, entries, &n_units);
+    auto grow = [&](void **buf, size_t *have, size_t need) -> int { // a lane's device buffers grow on demand (earlier launches of the lane may still read the old one)
+        if (need <= *have) return SVT_HIP_OK;
+        if (*buf) {
+            SVT_HIP_CHECK(ctx, hipStreamSynchronize(lane->stream));
+            (void)hipFree(*buf);
+            *buf = nullptr; *have = 0;
+        }
+        if (hipMalloc(buf, need) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "hipMalloc(%zu) failed (ME launch buffers)", need);
+        *have = need;
+        return SVT_HIP_OK;
+    };
     if (n_units) {
         const size_t need = (size_t)total * hdr.n_slot * SVT_HIP_ME_DENSE_KINDS * sizeof(MeDenseSlot);
-        if (need > lane->dense_bytes) {
-            if (lane->dense) {
-                SVT_HIP_CHECK(ctx, hipStreamSynchronize(lane->stream)); // earlier launches of this lane may still read the old buffer
-                hipFree(lane->dense);
-                lane->dense = nullptr; lane->dense_bytes = 0;
-            }
-            if (hipMalloc(&lane->dense, need) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "hipMalloc(%zu) failed (dense ME results)", need);
-            lane->dense_bytes = need;
-        }
+        if (int rc = grow(&lane->dense, &lane->dense_bytes, need)) return rc;
         SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->dense, 0xFF, need, lane->stream));
         hdr.dense = static_cast<MeDenseSlot *>(lane->dense);
         hdr.n_dense_entries = n_entries; hdr.n_dense_units = n_units;
     }
+    // With a pre-pass the per-block pipeline runs STAGED: small kernels cut at its searches, a block's state travelling through HBM between them
+    // (a launch of few blocks is bound by latency, not by throughput: the chain of nine short kernels costs it more than it gains)
+    const bool staged = n_units && (ctx->me_staged == 2 || (ctx->me_staged == 1 && total >= kStagedMinJobs));
+    if (staged) {
+        const size_t stage_bytes = (size_t)total * SVT_HIP_ME_STAGE_BYTES, words = (size_t)total * sizeof(uint32_t);
+        if (int rc = grow(&lane->stage, &lane->stage_bytes, stage_bytes + 4 * words)) return rc;
+        uint8_t *base = static_cast<uint8_t *>(lane->stage);
+        hdr.stage     = base;
+        hdr.job_flags = reinterpret_cast<uint32_t *>(base + stage_bytes);
+        for (int l = 0; l < 3; l++) hdr.lists[l] = reinterpret_cast<uint32_t *>(base + stage_bytes + (size_t)(1 + l) * words);
+        SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->queue_head + 128, 0, SVT_HIP_ME_QUEUE_BLOCK_BYTES - 128 * sizeof(uint32_t), lane->stream)); // the staged kernels' counters and the lists
+    }
     if (!ctx->me_attr_set) { // per context = per device; racing first calls set the same value
-        SVT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(svt_hip_me_b64_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)svt_hip_me_kernel_lds_bytes()));
+        const void *kernels[] = {reinterpret_cast<const void *>(svt_hip_me_b64_kernel),  reinterpret_cast<const void *>(svt_hip_me_mid1_kernel), reinterpret_cast<const void *>(svt_hip_me_s1_kernel),
+                                 reinterpret_cast<const void *>(svt_hip_me_s1f_kernel),  reinterpret_cast<const void *>(svt_hip_me_mid2_kernel), reinterpret_cast<const void *>(svt_hip_me_s2_kernel),
+                                 reinterpret_cast<const void *>(svt_hip_me_s2f_kernel),  reinterpret_cast<const void *>(svt_hip_me_tail_kernel)};
+        for (const void *k : kernels) SVT_HIP_CHECK(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)svt_hip_me_kernel_lds_bytes()));
         ctx->me_attr_set = true;
     }
-    // persistent waves: as many per CU as the LDS slices (the window arena + the launch's best_sad / best_mv rows) and the register
-    // budget of the launch bounds keep resident
-    const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift, hdr.dense ? 1 : 0).total + SVT_HIP_ME_PROFILE_LDS + 127) & ~(size_t)127;
-    uint32_t per_cu = (uint32_t)((160u * 1024u) / lds);
-    if (per_cu > 4u * SVT_HIP_ME_WAVES_PER_SIMD) per_cu = 4u * SVT_HIP_ME_WAVES_PER_SIMD;
-    if (ctx->me_waves_per_cu && per_cu > ctx->me_waves_per_cu) per_cu = ctx->me_waves_per_cu; // the caller leaves room for kernels of another stream
-    uint32_t grid = (uint32_t)ctx->num_cus * per_cu;
-    if (grid > total) grid = total;
     const int slot = lane->ring_next;
     lane->ring_next = (slot + 1) % SVT_HIP_PARAM_RING;
     SVT_HIP_CHECK(ctx, hipEventSynchronize(lane->params_copied[slot])); // the copy that last read this pinned block has run
@@ -2068,14 +2314,42 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     }
     SVT_HIP_CHECK(ctx, hipMemcpyAsync(dev, host, block_bytes, hipMemcpyHostToDevice, lane->stream));
     SVT_HIP_CHECK(ctx, hipEventRecord(lane->params_copied[slot], lane->stream));
+    const MeBatchHeader  *d_hdr = reinterpret_cast<const MeBatchHeader *>(dev);
+    const MeKernelParams *d_par = reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES);
     if (n_units) {
-        hipLaunchKernelGGL(svt_hip_me_dense_kernel, dim3(n_units), dim3(64), 0, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
-                           reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES), reinterpret_cast<const MeDenseEntry *>(dev + SVT_HIP_ME_ENTRIES_OFFSET));
+        hipLaunchKernelGGL(svt_hip_me_dense_kernel, dim3(n_units), dim3(64), 0, lane->stream, d_hdr, d_par, reinterpret_cast<const MeDenseEntry *>(dev + SVT_HIP_ME_ENTRIES_OFFSET));
         SVT_HIP_CHECK(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(svt_hip_me_b64_kernel, dim3(grid), dim3(64), lds, lane->stream, reinterpret_cast<const MeBatchHeader *>(dev),
-                       reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES));
+    // persistent waves: as many per CU as the kernel's LDS slice and the register budget of its launch bounds keep resident
+    auto launch = [&](void (*kernel)(const MeBatchHeader *, const MeKernelParams *, uint32_t), int mode, uint32_t waves_per_simd, uint32_t flags) {
+        const size_t lds = ((size_t)lds_layout((int)hdr.n_slot, (int)hdr.cshift, hdr.dense ? 1 : 0, mode).total + SVT_HIP_ME_PROFILE_LDS + 127) & ~(size_t)127;
+        uint32_t per_cu = (uint32_t)((160u * 1024u) / lds);
+        if (per_cu > 4u * waves_per_simd) per_cu = 4u * waves_per_simd;
+        if (ctx->me_waves_per_cu && per_cu > ctx->me_waves_per_cu) per_cu = ctx->me_waves_per_cu; // the caller leaves room for kernels of another stream
+        uint32_t grid = (uint32_t)ctx->num_cus * per_cu;
+        if (flags & 1u) grid = (uint32_t)ctx->num_cus * 2u; // list kernels: their lists are short (edge blocks), a wave's first atomic is its exit test when they are empty
+        if (grid > total) grid = total;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, lane->stream, d_hdr, d_par, flags);
+    };
+    if (staged) {
+        launch(svt_hip_me_mid1_kernel, kMeMid1, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
+        launch(svt_hip_me_s1_kernel, kMeS1, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
+        launch(svt_hip_me_s1f_kernel, kMeS1f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
+        launch(svt_hip_me_mid2_kernel, kMeMid2, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
+        launch(svt_hip_me_s2_kernel, kMeS2, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
+        launch(svt_hip_me_s2f_kernel, kMeS2f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
+        launch(svt_hip_me_tail_kernel, kMeTail, SVT_HIP_ME_TAIL_WAVES_PER_SIMD, 0u);
+        launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 1u); // the deferred blocks (usually none: the waves find an empty list and leave)
+    } else
+        launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 0u);
     SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_context_set_me_staged(SvtHipContext *ctx, int on) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    if (on < 0 || on > 2) return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "svt_hip_context_set_me_staged: %d is not 0 (off), 1 (large launches) or 2 (every launch)", on);
+    ctx->me_staged = on;
     return SVT_HIP_OK;
 }
 

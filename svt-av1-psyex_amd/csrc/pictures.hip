@@ -123,6 +123,7 @@ int svt_hip_context_create(SvtHipContext **out, int device) {
     ctx->device  = device;
     ctx->num_cus = prop.multiProcessorCount;
     { const char *e = getenv("SVT_HIP_ME_DENSE"); ctx->me_dense = !(e && e[0] == '0'); }
+    { const char *e = getenv("SVT_HIP_ME_STAGED"); ctx->me_staged = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
     // lane 0 (the asynchronous entries' stream) and this device's transform tables exist from the start; the borrowed
     // lanes are made when a synchronous entry first needs one
     if (svt_hip_lane_setup(ctx, &ctx->lane[0], true) != SVT_HIP_OK || svt_hip_rd_tables_init(ctx) != SVT_HIP_OK) {
@@ -143,6 +144,7 @@ void svt_hip_context_destroy(SvtHipContext *ctx) {
         if (l.stream) hipStreamSynchronize(l.stream);
         if (l.scratch) hipFree(l.scratch);
         if (l.dense) hipFree(l.dense);
+        if (l.stage) hipFree(l.stage);
         if (l.queue_head) hipFree(l.queue_head);
         if (l.params_dev) hipFree(l.params_dev);
         for (int k = 0; k < SVT_HIP_PARAM_RING; k++) {
@@ -277,8 +279,8 @@ int svt_hip_lane_setup(SvtHipContext *ctx, SvtHipLane *l, bool make_stream) {
     // a set-up that failed part-way is retried by the lane's next holder: only the objects that do not exist yet are made
     if (make_stream && !l->stream) SVT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
     if (!l->queue_head) {
-        if (hipMalloc(reinterpret_cast<void **>(&l->queue_head), 512) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMalloc failed");
-        if (hipMemset(l->queue_head, 0, 512) != hipSuccess) { hipFree(l->queue_head); l->queue_head = nullptr; return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMemset failed"); }
+        if (hipMalloc(reinterpret_cast<void **>(&l->queue_head), SVT_HIP_ME_QUEUE_BLOCK_BYTES) != hipSuccess) return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMalloc failed");
+        if (hipMemset(l->queue_head, 0, SVT_HIP_ME_QUEUE_BLOCK_BYTES) != hipSuccess) { hipFree(l->queue_head); l->queue_head = nullptr; return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMemset failed"); }
     }
     if (!l->params_dev && hipMalloc(reinterpret_cast<void **>(&l->params_dev), SVT_HIP_ME_PARAM_BYTES) != hipSuccess)
         return svt_hip_fail(ctx, SVT_HIP_ERR_NO_MEMORY, "lane set-up: hipMalloc failed");

@@ -21,7 +21,7 @@
 
 struct SvtHipLane {
     hipStream_t stream;
-    uint32_t   *queue_head;  // SVT_HIP_ME_QUEUES counters in HBM (+ the profiling build's phase sums)
+    uint32_t   *queue_head;  // SVT_HIP_ME_QUEUE_BLOCK_BYTES: job-queue counters of the ME kernels, the profiling build's phase sums, list cursors (me_kernel.h)
     uint8_t    *params_dev;  // MeBatchHeader (SVT_HIP_ME_HEADER_BYTES) + MeKernelParams[SVT_HIP_ME_MAX_PICTURES]
     uint8_t    *params_host[SVT_HIP_PARAM_RING];   // pinned staging copies of the same block
     hipEvent_t  params_copied[SVT_HIP_PARAM_RING]; // recorded behind the H2D copy that reads params_host[i]
@@ -30,6 +30,8 @@ struct SvtHipLane {
     size_t      scratch_bytes;
     void       *dense;       // slots of the ME dense pre-pass (me_dense.inl), grown on demand
     size_t      dense_bytes;
+    void       *stage;       // staged ME launches: the blocks' travelling records, flag words and the three job lists
+    size_t      stage_bytes;
     bool        ready;       // device objects exist (lanes are set up on first use)
 };
 
@@ -44,6 +46,7 @@ struct SvtHipContext {
     uint32_t    lane_busy;             // bit i: lane i is borrowed
     int16_t    *iscan_dev;             // [19][3][1024] inverse scan orders (rd_kernel.hip), this device's copy
     bool        me_attr_set;           // hipFuncSetAttribute done for the ME kernel on this device
+    int         me_staged;             // with a pre-pass, the per-block pipeline runs as a chain of small kernels: 0 never, 1 launches of many blocks, 2 always (svt_hip_context_set_me_staged)
     bool        me_dense;              // the dense pre-HME / level-0 pre-pass runs ahead of the per-block ME kernel (svt_hip_context_set_me_dense)
     uint32_t    me_waves_per_cu;       // 0: as many persistent ME waves per CU as fit; else an upper limit (svt_hip_context_set_me_waves_per_cu)
     hipStream_t io_stream;             // transfer stream of svt_hip_pa_picture_update_ahead (created on first use)

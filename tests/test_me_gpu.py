@@ -9,6 +9,15 @@ from test_oracle_vs_ref import ME_GRID
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True, params=[0, 2], ids=["one-kernel", "staged"])
+def me_form(request, hip_ctx):
+    """Every test of this module runs with the per-block pipeline in both forms (the default picks by launch size: small test pictures
+    would never reach the staged kernels)."""
+    hip_ctx.set_me_staged(request.param)
+    yield request.param
+    hip_ctx.set_me_staged(1)
+
+
 @pytest.mark.parametrize("name", me_fixture_names())
 def test_hip_matches_reference_fixture(hip_ctx, name):
     case = GoldenMeCase(name)
@@ -231,7 +240,7 @@ DENSE_CASES = [
 
 
 @pytest.mark.parametrize("kw", DENSE_CASES, ids=lambda k: f"{k['width']}x{k['height']}_m{k['enc_mode']}")
-def test_dense_prepass_is_used_and_changes_nothing(hip_ctx, kw):
+def test_dense_prepass_is_used_and_changes_nothing(hip_ctx, me_form, kw):
     """With the pre-pass on, the per-block kernel takes pre-HME / level-0 results from it (counter > 0) and every output -- the
     search-level arrays included -- equals the run without it and the oracle."""
     case = MeCase(**kw)
@@ -242,13 +251,20 @@ def test_dense_prepass_is_used_and_changes_nothing(hip_ctx, kw):
         off = case.run_hip(hip_ctx)
         assert hip_ctx.me_dense_counters() == (0, 0)
         hip_ctx.set_me_dense(True)
+        hip_ctx.set_me_staged(0)  # pre-pass + the one-kernel pipeline
         on = case.run_hip(hip_ctx)
         taken, own = hip_ctx.me_dense_counters()
+        hip_ctx.set_me_staged(2)   # pre-pass + the chain of small kernels (+ the one-kernel form for deferred blocks)
+        staged = case.run_hip(hip_ctx)
+        taken_s, own_s = hip_ctx.me_dense_counters()
     finally:
         hip_ctx.set_me_dense(True)
+        hip_ctx.set_me_staged(me_form)
     assert not compare(want, off)
     assert not compare(want, on)
+    assert not compare(want, staged)
     assert taken > 0 and taken > 4 * own, (taken, own)
+    assert taken_s >= taken, (taken_s, taken)  # what the one-kernel form took from the pre-pass the staged form takes too (a deferred block takes its slots twice)
 
 
 def test_dense_prepass_skip_search_line_and_partial_octets(hip_ctx):
