@@ -704,6 +704,17 @@ def main():
     # per kernel family: the median over the pass's launches (one disturbed launch -- a clock ramp, a neighbour on the PCIe switch -- would
     # otherwise move a mean of six by a multiple)
     kms = {k: float(np.median([s.elapsed_time(e) for s, e in v])) for k, v in ev.items()}
+    # the kernels of the ME launch one by one: the library brackets them with events of its own on the launch stream when asked to
+    # (svt_hip_context_set_me_timing; off in the timed loop)
+    chain = []
+    if wl.live:
+        ctx.set_me_timing(True)
+        for _ in range(max(N_SETS, 3)):
+            run(1)
+            chain.append(ctx.me_launch_times())
+        ctx.set_me_timing(False)
+        barrier()
+    chain_ms = {k: float(np.median([c.get(k, 0.0) for c in chain])) for k in (chain[0] if chain else {})}
     gather_check = None
     if world > 1:
         while (step_no[0] - 1) % N_SETS != 0:
@@ -807,10 +818,10 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (same command, N = 1): rocprofv3 cannot run
         # inside this process, so the figure is the recorded one; null when it does not describe this run
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
         if world == 1 and os.path.exists(tf):
-            traffic = json.load(open(tf))["kernels"].get("svt_hip_me_b64_kernel", {}).get("hbm_bytes_per_launch")
-            traffic_src = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+            traffic = json.load(open(tf))["kernels"].get("me_launch", {}).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/r03_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; the kernels of the ME launch summed)"
         ach = me_bytes / (kms["me"] * 1e-3) / 1e9
         rd_roof = {}
         for ts, descs, _, _, n, _ in wl.rd:
@@ -828,10 +839,14 @@ def main():
                                    f"{N_SETS} picture sets alternate from step to step",
                        "pictures_per_step": len(PICS), "b64_rows_per_rank_per_step": wl.rows_per_step,
                        "parallelism": f"b64-row bands x{world} (left-over rows rotating over the ranks) + all-gather of ME results" + (f" via {xch.kind}" if xch else "")},
-            "roofline": {"bound": "hbm", "kernel": "svt_hip_me_b64_kernel", "achieved": round(ach, 2),
+            "roofline": {"bound": "hbm", "kernel": "ME launch = " + " -> ".join(k.replace("svt_hip_me_", "").replace("_kernel", "") for k in chain_ms) + " (svt_hip_me_*_kernel, one stream)",
+                         "kernel_chain_ms": {k: round(v, 4) for k, v in chain_ms.items()}, "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(me_bytes), "avg_launch_ms": round(kms["me"], 4),
-                         "note": "by the task's rule the bound is HBM; the search is issue-bound (SURVEY 8d): see valu_sad below", "longest_kernel": dom},
+                         "note": "the ME of a step is ONE launch of the C entry = a chain of kernels on one stream (dense pre-pass, then the per-block pipeline staged at its searches); "
+                                 "avg_launch_ms brackets the chain (HIP events on the launch stream), kernel_chain_ms each kernel (events the library records between them in a "
+                                 "separate pass; profiles/r03_kernel_stats_bench.csv has rocprofv3's averages of the same kernels).  By the task's rule the bound is HBM; the search "
+                                 "is issue-bound (SURVEY 8d): see valu_sad below", "longest_kernel": dom},
             "rd_roofline": rd_roof,
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
         }

@@ -193,6 +193,14 @@ int   svt_hip_context_set_me_dense(SvtHipContext *ctx, int on);
  * end of the launch.  on = 0: never; 1 (default): launches of 4096 blocks and more (a small launch is latency-bound: one kernel serves it
  * better than nine); 2: every launch.  SVT_HIP_ME_STAGED=0/1/2 sets it at context creation.  Results are identical either way. */
 int   svt_hip_context_set_me_staged(SvtHipContext *ctx, int on);
+/* Measurement aid: with timing on, an ME launch records events around each kernel of its chain, and svt_hip_me_launch_times returns the
+ * durations (ms) of the LAST launch enqueued on the context stream (it waits for that launch): ms[i] for kernel i of
+ * svt_hip_me_chain_kernel_name(i) -- 0 for kernels the launch did not use (the one-kernel form uses the pre-pass and svt_hip_me_b64_kernel
+ * only).  The events cost a few microseconds per kernel: off by default. */
+#define SVT_HIP_ME_CHAIN_KERNELS 9
+int   svt_hip_context_set_me_timing(SvtHipContext *ctx, int on);
+int   svt_hip_me_launch_times(SvtHipContext *ctx, float ms[SVT_HIP_ME_CHAIN_KERNELS]);
+const char *svt_hip_me_chain_kernel_name(int i);
 /* Diagnostics: out[0] = searches the per-block kernel took from the pre-pass, out[1] = searches it made itself although the pre-pass was
  * on (edge blocks, configurations the pre-pass does not cover), since the last call; waits for the context's streams. */
 int   svt_hip_me_dense_counters(SvtHipContext *ctx, unsigned long long out[2]);

@@ -118,6 +118,18 @@ class Context:
         """with the pre-pass on: the per-block pipeline as a chain of small kernels (svt_hip_context_set_me_staged): 0 never, 1 launches of many blocks (default), 2 always; results are identical either way"""
         self.check(lib().svt_hip_context_set_me_staged(self._h, int(on)), "svt_hip_context_set_me_staged")
 
+    def set_me_timing(self, on):
+        """ME launches record events around the kernels of their chain (svt_hip_context_set_me_timing)"""
+        self.check(lib().svt_hip_context_set_me_timing(self._h, 1 if on else 0), "svt_hip_context_set_me_timing")
+
+    def me_launch_times(self):
+        """{kernel name: ms} of the last ME launch on the context stream (svt_hip_me_launch_times; waits for the launch); kernels it did not use are left out"""
+        L = lib()
+        ms = (C.c_float * 9)()
+        self.check(L.svt_hip_me_launch_times(self._h, ms), "svt_hip_me_launch_times")
+        L.svt_hip_me_chain_kernel_name.restype = C.c_char_p
+        return {L.svt_hip_me_chain_kernel_name(i).decode(): float(ms[i]) for i in range(9) if ms[i] > 0}
+
     def me_dense_counters(self):
         """(searches taken from the dense pre-pass, searches the per-block kernel made itself) since the last call"""
         v = (C.c_ulonglong * 2)()

@@ -736,12 +736,13 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
 // (piece n = owner n / NV, part n % NV: the NV lanes of a row side by side in one or two lines), hands them over through the arena, and
 // every owner reads its row back with NV ds_read_b128 (lane stride NV x 16 bytes, NV odd: conflict-free).  The next step's pieces are on
 // their way while the current one is evaluated.  `wp` = the owner's first window row (idle lanes: rows <= 0), `wstep` uniform.
-template <int NDW>
+template <int NDW, int DEPTH>
 __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, int sp, int srs, const uint8_t *wp, long long wstep, int e0, int rows, int rows_max, uint32_t out[8]) {
     constexpr int NV = (NDW + 2 + 3) / 4, kRowsPerFlush = 64 / NDW;
     static_assert(NV & 1, "owners read their pieces back without bank conflicts");
+    static_assert(DEPTH == 1 || DEPTH == 2, "steps in flight");
     const int lane = threadIdx.x;
-    const uint8_t *pp[NV]; // where this lane fetches piece (lane + 64 k) of a step
+    const uint8_t *pp[NV]; // where this lane fetches piece (lane + 64 k) of the next step to request
     int            pn[NV]; // steps its owner makes
 #pragma unroll
     for (int k = 0; k < NV; k++) {
@@ -751,19 +752,26 @@ __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, 
         pn[k] = __shfl(rows, owner, 64);
     }
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    V4U v[NV];
-#pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = pn[k] > 0 ? *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k])) : V4U{0, 0, 0, 0};
-    u64 acc0 = 0, acc1 = 0;
-    for (int t = 0; t < rows_max; t++) { // uniform
-#pragma unroll
-        for (int k = 0; k < NV; k++) *reinterpret_cast<V4U *>(arena + 16 * (lane + 64 * k)) = v[k];
-        wave_sync();
+    V4U v[DEPTH][NV];
+    auto request = [&](V4U (&r)[NV], int step) { // the pieces of `step` (requests are made in step order: pp walks along)
 #pragma unroll
         for (int k = 0; k < NV; k++) {
+            if (step < pn[k]) r[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k]));
             pp[k] += wstep;
-            if (t + 1 < pn[k]) v[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k]));
         }
+    };
+#pragma unroll
+    for (int dpt = 0; dpt < DEPTH; dpt++) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[dpt][k] = V4U{0, 0, 0, 0};
+        request(v[dpt], dpt);
+    }
+    u64 acc0 = 0, acc1 = 0;
+    auto step = [&](V4U (&r)[NV], int t) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) *reinterpret_cast<V4U *>(arena + 16 * (lane + 64 * k)) = r[k];
+        wave_sync();
+        request(r, t + DEPTH);
         if (t < rows) {
             const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (e0 + t) * srs * sp);
             uint32_t sv[NDW], wv[4 * NV];
@@ -789,6 +797,10 @@ __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, 
             acc0 = acc1 = 0;
         }
         wave_sync(); // the arena is rewritten
+    };
+    for (int t = 0; t < rows_max; t += DEPTH) { // uniform
+        step(v[0], t);
+        if (DEPTH == 2 && t + 1 < rows_max) step(v[DEPTH - 1], t + 1);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = a[i];
@@ -808,7 +820,7 @@ __device__ __forceinline__ bool small_direct_ok(const St &st) {
     if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
     return ((w + 7) >> 3) * h * nreq <= kThreads; // octet items of one slice
 }
-__device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
+template <int DEPTH = 1> __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
     St       &st   = sh.st;
     const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
     // every search like the first one, few positions, whole-vector source rows
@@ -838,8 +850,8 @@ __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM)
         wp   = r.win + (long long)y * r.stride + (long long)e0 * wstep + 8 * g;
     }
     uint32_t s8[8];
-    if (bw == 64) direct_rows<16>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
-    else direct_rows<8>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    if (bw == 64) direct_rows<16, DEPTH>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    else direct_rows<8, DEPTH>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
     for (int p = lane; p < nreq * kNarrowMaxPos; p += kThreads) sad[p] = 0;
     wave_sync();
     if (mine) {
@@ -1362,7 +1374,7 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
             wave_sync();
             if (st.nreq) { // uniform
                 if constexpr (me_is_staged_search(MODE)) run_searches(sh PROF_ARG);
-                else (void)run_small_searches_direct(sh PROF_ARG); // (the Mid kernel routed the block here because it qualifies)
+                else (void)run_small_searches_direct(sh PROF_ARG); // (two steps of rows in flight -- DEPTH 2, the kernel has the registers -- measured no faster: 0.387 vs 0.390 ms; the Mid kernel routed the block here because it qualifies)
             }
             wave_sync();
             u64 *keys = keys_of(gjob);
@@ -2316,7 +2328,18 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     SVT_HIP_CHECK(ctx, hipEventRecord(lane->params_copied[slot], lane->stream));
     const MeBatchHeader  *d_hdr = reinterpret_cast<const MeBatchHeader *>(dev);
     const MeKernelParams *d_par = reinterpret_cast<const MeKernelParams *>(dev + SVT_HIP_ME_HEADER_BYTES);
+    // svt_hip_context_set_me_timing: an event in front of every kernel of the chain (me_mark[kernel]) and one behind the last (me_mark[9])
+    const bool timing = ctx->me_timing;
+    lane->me_marked = 0;
+    auto mark = [&](int kernel) { // kernel < 0: the closing event
+        if (!timing) return;
+        const int i = kernel < 0 ? SVT_HIP_ME_CHAIN_KERNELS : kernel;
+        if (!lane->me_mark[i]) hipEventCreate(&lane->me_mark[i]);
+        hipEventRecord(lane->me_mark[i], lane->stream);
+        if (kernel >= 0) lane->me_marked |= 1u << kernel;
+    };
     if (n_units) {
+        mark(0);
         hipLaunchKernelGGL(svt_hip_me_dense_kernel, dim3(n_units), dim3(64), 0, lane->stream, d_hdr, d_par, reinterpret_cast<const MeDenseEntry *>(dev + SVT_HIP_ME_ENTRIES_OFFSET));
         SVT_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -2332,17 +2355,46 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, lane->stream, d_hdr, d_par, flags);
     };
     if (staged) {
-        launch(svt_hip_me_mid1_kernel, kMeMid1, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
-        launch(svt_hip_me_s1_kernel, kMeS1, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
-        launch(svt_hip_me_s1f_kernel, kMeS1f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
-        launch(svt_hip_me_mid2_kernel, kMeMid2, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
-        launch(svt_hip_me_s2_kernel, kMeS2, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
-        launch(svt_hip_me_s2f_kernel, kMeS2f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
-        launch(svt_hip_me_tail_kernel, kMeTail, SVT_HIP_ME_TAIL_WAVES_PER_SIMD, 0u);
-        launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 1u); // the deferred blocks (usually none: the waves find an empty list and leave)
-    } else
-        launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 0u);
+        mark(1); launch(svt_hip_me_mid1_kernel, kMeMid1, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
+        mark(2); launch(svt_hip_me_s1_kernel, kMeS1, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
+        mark(3); launch(svt_hip_me_s1f_kernel, kMeS1f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
+        mark(4); launch(svt_hip_me_mid2_kernel, kMeMid2, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
+        mark(5); launch(svt_hip_me_s2_kernel, kMeS2, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
+        mark(6); launch(svt_hip_me_s2f_kernel, kMeS2f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
+        mark(7); launch(svt_hip_me_tail_kernel, kMeTail, SVT_HIP_ME_TAIL_WAVES_PER_SIMD, 0u);
+        mark(8); launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 1u); // the deferred blocks (usually none: the waves find an empty list and leave)
+    } else {
+        mark(8); launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 0u);
+    }
+    mark(-1);
     SVT_HIP_CHECK(ctx, hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+static const char *const kChainKernelNames[SVT_HIP_ME_CHAIN_KERNELS] = {"svt_hip_me_dense_kernel", "svt_hip_me_mid1_kernel", "svt_hip_me_s1_kernel",  "svt_hip_me_s1f_kernel", "svt_hip_me_mid2_kernel",
+                                                                        "svt_hip_me_s2_kernel",    "svt_hip_me_s2f_kernel",  "svt_hip_me_tail_kernel", "svt_hip_me_b64_kernel"};
+extern "C" const char *svt_hip_me_chain_kernel_name(int i) { return i >= 0 && i < SVT_HIP_ME_CHAIN_KERNELS ? kChainKernelNames[i] : nullptr; }
+
+extern "C" int svt_hip_context_set_me_timing(SvtHipContext *ctx, int on) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    ctx->me_timing = on != 0;
+    return SVT_HIP_OK;
+}
+
+// the kernels of the last launch enqueued through lane 0 (the context stream)
+extern "C" int svt_hip_me_launch_times(SvtHipContext *ctx, float ms[SVT_HIP_ME_CHAIN_KERNELS]) {
+    if (!ctx || !ms) return SVT_HIP_ERR_BAD_PARAM;
+    SvtHipLane &l = ctx->lane[0];
+    hipSetDevice(ctx->device);
+    SVT_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
+    for (int i = 0; i < SVT_HIP_ME_CHAIN_KERNELS; i++) {
+        ms[i] = 0.f;
+        if (!(l.me_marked >> i & 1u)) continue;
+        // the event behind kernel i is the next one recorded: the one in front of the next kernel that ran, or the closing event
+        int j = i + 1;
+        while (j < SVT_HIP_ME_CHAIN_KERNELS && !(l.me_marked >> j & 1u)) j++;
+        SVT_HIP_CHECK(ctx, hipEventElapsedTime(&ms[i], l.me_mark[i], l.me_mark[j]));
+    }
     return SVT_HIP_OK;
 }
 

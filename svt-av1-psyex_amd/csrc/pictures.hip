@@ -145,6 +145,7 @@ void svt_hip_context_destroy(SvtHipContext *ctx) {
         if (l.scratch) hipFree(l.scratch);
         if (l.dense) hipFree(l.dense);
         if (l.stage) hipFree(l.stage);
+        for (hipEvent_t &e : l.me_mark) if (e) hipEventDestroy(e);
         if (l.queue_head) hipFree(l.queue_head);
         if (l.params_dev) hipFree(l.params_dev);
         for (int k = 0; k < SVT_HIP_PARAM_RING; k++) {

@@ -32,6 +32,8 @@ struct SvtHipLane {
     size_t      dense_bytes;
     void       *stage;       // staged ME launches: the blocks' travelling records, flag words and the three job lists
     size_t      stage_bytes;
+    hipEvent_t  me_mark[SVT_HIP_ME_CHAIN_KERNELS + 1]; // svt_hip_context_set_me_timing: events around the kernels of the last ME launch (created on first use)
+    uint32_t    me_marked;   // bit i: kernel i of the chain ran in the last launch (me_mark[i] .. me_mark[i + 1] bracket it)
     bool        ready;       // device objects exist (lanes are set up on first use)
 };
 
@@ -47,6 +49,7 @@ struct SvtHipContext {
     int16_t    *iscan_dev;             // [19][3][1024] inverse scan orders (rd_kernel.hip), this device's copy
     bool        me_attr_set;           // hipFuncSetAttribute done for the ME kernel on this device
     int         me_staged;             // with a pre-pass, the per-block pipeline runs as a chain of small kernels: 0 never, 1 launches of many blocks, 2 always (svt_hip_context_set_me_staged)
+    bool        me_timing;             // ME launches record events around their kernels (svt_hip_context_set_me_timing)
     bool        me_dense;              // the dense pre-HME / level-0 pre-pass runs ahead of the per-block ME kernel (svt_hip_context_set_me_dense)
     uint32_t    me_waves_per_cu;       // 0: as many persistent ME waves per CU as fit; else an upper limit (svt_hip_context_set_me_waves_per_cu)
     hipStream_t io_stream;             // transfer stream of svt_hip_pa_picture_update_ahead (created on first use)

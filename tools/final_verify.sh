@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end verification on the GPU box: full GPU suite, smoke, the bench line, and the rocprofv3 passes profiles/ is built from.
 # Run through gpurun from the repo root; outputs land in gpurun_out/ (then: python3 tools/refresh_profiles.py).
-R=${SVT_ROUND:-r02}
+R=${SVT_ROUND:-r03}
 set -e -o pipefail
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null

@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 CMD = "python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras"
 
 
@@ -19,8 +19,8 @@ def one(pattern):
 
 
 def short(k):
-    if 'me_b64' in k:
-        return 'svt_hip_me_b64_kernel'
+    if 'svt_hip_me_' in k:
+        return 'svt_hip_me_' + k.split('svt_hip_me_')[1].split('_kernel')[0] + '_kernel'
     if 'rd_tx_kernel' in k:
         return 'rd_tx_kernel<%s>' % k.split('rd_tx_kernel<')[1].split('>')[0]
     if 'fullpel' in k:
@@ -44,18 +44,24 @@ for d, cn in ((R + 'f', 'FETCH_SIZE'), (R + 'w', 'WRITE_SIZE')):
             out["kernels"].setdefault(short(k), {})[cn + "_KiB"] = round(sum(v) / len(v), 1)
             out["kernels"][short(k)]["launches"] = len(v)
 for k, v in out["kernels"].items():
-    f = 2 if k == 'svt_hip_me_b64_kernel' else 1
-    v["hbm_bytes_per_launch"] = int((f * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024)
-alg = {"svt_hip_me_b64_kernel": b["roofline"]["algorithmic_bytes_per_launch"], **{k: v["algorithmic_bytes_per_launch"] for k, v in b["rd_roofline"].items()}}
+    f = 2 if k.startswith('svt_hip_me_') else 1
+    v["hbm_bytes_per_launch"] = int((f * v.get("FETCH_SIZE_KiB", 0) + v.get("WRITE_SIZE_KiB", 0)) * 1024)
+# the ME of a step is one launch of the C entry = a chain of kernels: their bytes summed (every kernel runs once per launch)
+chain = [k for k in out["kernels"] if k.startswith('svt_hip_me_')]
+out["kernels"]["me_launch"] = {"kernels": chain, "hbm_bytes_per_launch": sum(out["kernels"][k]["hbm_bytes_per_launch"] for k in chain)}
+alg = {"me_launch": b["roofline"]["algorithmic_bytes_per_launch"], **{k: v["algorithmic_bytes_per_launch"] for k, v in b["rd_roofline"].items()}}
+TX = {"4": "64x64", "3": "32x32", "2": "16x16"}  # TxSize enumerators of the instantiations bench.py launches
 for k, v in out["kernels"].items():
-    kk = k.replace("(TxSize)", "").replace(", 10>", ", 10>")
-    for a, by in alg.items():
-        if a.split('<')[0] == k.split('<')[0] and (a == k or a.split('<')[-1].split(',')[0] in k or k == 'svt_hip_me_b64_kernel'):
-            v["algorithmic_bytes_per_launch"] = by
-            v["traffic_over_algorithmic"] = round(v["hbm_bytes_per_launch"] / by, 2)
-            break
+    a = k
+    if k.startswith('rd_tx_kernel<'):
+        ts = k.split('<')[1].split(',')[0].replace('(TxSize)', '').strip()
+        a = f"rd_tx_kernel<{TX.get(ts, ts)}, 10>"
+        v["bench_name"] = a
+    if a in alg:
+        v["algorithmic_bytes_per_launch"] = alg[a]
+        v["traffic_over_algorithmic"] = round(v["hbm_bytes_per_launch"] / alg[a], 2)
 json.dump(out, open(f'profiles/{R}_hbm_traffic.json', 'w'), indent=1)
-b['roofline']['traffic'] = out['kernels']['svt_hip_me_b64_kernel']['hbm_bytes_per_launch']  # the PMC passes of this very verification run
+b['roofline']['traffic'] = out['kernels']['me_launch']['hbm_bytes_per_launch']  # the PMC passes of this very verification run
 json.dump(b, open(f'profiles/{R}_bench_final.json', 'w'), indent=1)
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(one(f'gpurun_out/{R}q/**/*counter_collection.csv'))):
@@ -63,17 +69,16 @@ for r in csv.DictReader(open(one(f'gpurun_out/{R}q/**/*counter_collection.csv'))
         acc[(short(r['Kernel_Name']), r['Counter_Name'])].append(float(r['Counter_Value']))
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
 kern = sorted({kk[0] for kk in avg})
-busy = {k: 4 * avg[(k, 'SQ_ACTIVE_INST_VALU')] / 1024 / (avg[(k, 'SQ_BUSY_CYCLES')] / 32) for k in kern}
+busy = {k: 4 * avg[(k, 'SQ_ACTIVE_INST_VALU')] / 1024 / (avg[(k, 'SQ_BUSY_CYCLES')] / 32) for k in kern if avg[(k, 'SQ_BUSY_CYCLES')] > 0}
 wait = {k: avg[(k, 'SQ_WAIT_ANY')] / avg[(k, 'SQ_WAVE_CYCLES')] for k in kern}
 with open(f'profiles/{R}_sq_counters.txt', 'w') as f:
     f.write(f"rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD -- {CMD}\n")
     f.write("average per launch (one launch = the 16 pictures of a step = 32,640 blocks of 64x64 for the ME kernel); *_CYCLES / ACTIVE / WAIT counters are in quad-cycles per wave (x4 = clocks); SQ_BUSY_CYCLES summed over 32 shader engines\n")
     f.write("derived: VALU busy per SIMD = 4*SQ_ACTIVE_INST_VALU/1024 / (SQ_BUSY_CYCLES/32): " + ", ".join(f"{k} {100 * v:.0f} %" for k, v in sorted(busy.items())) + "\n")
     f.write("derived: share of wave-cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES): " + ", ".join(f"{k} {100 * v:.0f} %" for k, v in sorted(wait.items())) + "\n")
-    me = 'svt_hip_me_b64_kernel'
-    if (me, 'SQ_INSTS_VALU') in avg:
-        nb = 32640.0
-        f.write("derived: ME kernel wave-instructions per 64x64 block: " + ", ".join(f"{c[9:]} {avg[(me, c)] / nb:.0f}" for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD')) + "\n")
+    nb = 32640.0
+    mek = [k for k in kern if k.startswith('svt_hip_me_')]
+    f.write("derived: ME launch (its kernels summed) wave-instructions per 64x64 block: " + ", ".join(f"{c[9:]} {sum(avg[(k, c)] for k in mek) / nb:.0f}" for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD')) + "\n")
     f.write("\n")
     for k in sorted(avg):
         f.write(f"{k[0]:28s} {k[1]:22s} {avg[k]:.4g}\n")
