@@ -85,6 +85,14 @@ __device__ __forceinline__ void had_col8(const int16_t *s, int st, int16_t *o) {
     o[4] = (int16_t)(c[3] + c[7]); o[5] = (int16_t)(c[3] - c[7]);
 }
 
+// Every wave of these kernels works on LDS tiles of its own: a wave's LDS instructions execute in order, so what orders a lane's reads behind
+// another lane's writes is a compiler-level barrier only (a workgroup barrier would also tie together waves that share a workgroup but not a job).
+__device__ __forceinline__ void stats_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int kResPitch = 34; // int16 row pitch of the residual tile in LDS (17 dwords: rows land on different banks)
 
 struct HadLds {
@@ -98,13 +106,13 @@ struct HadLds {
 __device__ void hadamard_tile(HadLds &L, int n, int lane) {
     if (n == 4) {
         if (lane < 4) had_col4(L.res + lane, kResPitch, L.t + 4 * lane);
-        __syncthreads();
+        stats_wave_sync();
         if (lane < 4) {
             int16_t o[4];
             had_col4(L.t + lane, 4, o);
             for (int k = 0; k < 4; k++) L.c[4 * lane + k] = o[k];
         }
-        __syncthreads();
+        stats_wave_sync();
         return;
     }
     const int nb = n >> 3; // 8x8 sub-blocks per side
@@ -118,7 +126,7 @@ __device__ void hadamard_tile(HadLds &L, int n, int lane) {
         const int i = it & 7, sb = it >> 3, by = sb / nb, bx = sb - by * nb;
         had_col8(L.res + (8 * by) * kResPitch + 8 * bx + i, kResPitch, L.t + base_of(by, bx) + 8 * i);
     }
-    __syncthreads();
+    stats_wave_sync();
     for (int it = lane; it < nb * nb * 8; it += 64) { // second pass: rows of the intermediate
         const int i = it & 7, sb = it >> 3, by = sb / nb, bx = sb - by * nb;
         const int base = base_of(by, bx);
@@ -126,7 +134,7 @@ __device__ void hadamard_tile(HadLds &L, int n, int lane) {
         had_col8(L.t + base + i, 8, o);
         for (int k = 0; k < 8; k++) L.c[base + 8 * i + k] = o[k];
     }
-    __syncthreads();
+    stats_wave_sync();
     auto combine = [&](int32_t *c, int cn, int shift, int i) {
         const int32_t a0 = c[i], a1 = c[cn + i], a2 = c[2 * cn + i], a3 = c[3 * cn + i];
         const int32_t b0 = (a0 + a1) >> shift, b1 = (a0 - a1) >> shift, b2 = (a2 + a3) >> shift, b3 = (a2 - a3) >> shift;
@@ -135,11 +143,11 @@ __device__ void hadamard_tile(HadLds &L, int n, int lane) {
     if (n >= 16) {
         const int n16 = (n == 16) ? 1 : 4;
         for (int it = lane; it < n16 * 64; it += 64) combine(L.c + 256 * (it >> 6), 64, 1, it & 63);
-        __syncthreads();
+        stats_wave_sync();
     }
     if (n == 32) {
         for (int it = lane; it < 256; it += 64) combine(L.c, 256, 2, it);
-        __syncthreads();
+        stats_wave_sync();
     }
 }
 
@@ -345,6 +353,7 @@ template <typename Pix> __device__ int32_t psy_tile_energy(const View<Pix> &pv, 
 
 struct StatsParams {
     SvtHipBlockStatsDesc d;
+    uint32_t n_front; // workgroups [0, n_front) of the launch take the regions (d.pyramids), the rest the flat jobs
 };
 
 constexpr int kJobsPerWave = 4; // a multiple of 4, at most 16 (the psy prefix sum runs inside one DPP row).  Measured: 16 jobs per wave bring the 2160p psy batch from 0.29 to 0.21 ms but the 1080p statistics batch from 0.065 to 0.22 ms (sixteen 64x64 blocks in a row make a long, lonely wave)
@@ -453,13 +462,13 @@ __device__ __forceinline__ void block_stats_job(const StatsParams &p, HadLds &L,
                             const int r = i / n, c = i - r * n;
                             L.res[r * kResPitch + c] = (int16_t)((int16_t)src.at(ty + r, tx + c) - (int16_t)ref.at(ty + r, tx + c));
                         }
-                    __syncthreads();
+                    stats_wave_sync();
                     if (n >= 16) satd += hadamard_satd_mfma(L, n, lane); // uniform
                     else {
                         hadamard_tile(L, n, lane);
                         for (int i = lane; i < n * n; i += 64) { const int32_t v = L.c[i]; satd += (uint32_t)(v < 0 ? -v : v); }
                     }
-                    __syncthreads();
+                    stats_wave_sync();
                 }
         }
         satd = wave_sum(satd);
@@ -467,11 +476,15 @@ __device__ __forceinline__ void block_stats_job(const StatsParams &p, HadLds &L,
     }
 }
 
-template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel(const StatsParams p) {
-    __shared__ HadLds   L;
-    __shared__ uint32_t tile0[kJobsPerWave + 1], esum[kJobsPerWave]; // psy: first tile of each job in the wave's tile sequence, energy sums
-    const int      lane = threadIdx.x;
-    const uint32_t j0 = blockIdx.x * kJobsPerWave, j1 = j0 + kJobsPerWave < p.d.n_jobs ? j0 + kJobsPerWave : p.d.n_jobs;
+struct FlatLds { // one wave's tiles
+    HadLds   L;
+    uint32_t tile0[kJobsPerWave + 1], esum[kJobsPerWave]; // psy: first tile of each job in the wave's tile sequence, energy sums
+};
+// jobs [wave * kJobsPerWave, ...) of the flat list, by one wave
+template <typename Pix> __device__ __forceinline__ void block_stats_flat(const StatsParams &p, FlatLds &F, const uint32_t wave, const int lane) {
+    HadLds   &L = F.L;
+    uint32_t *tile0 = F.tile0, *esum = F.esum;
+    const uint32_t j0 = wave * kJobsPerWave, j1 = j0 + kJobsPerWave < p.d.n_jobs ? j0 + kJobsPerWave : p.d.n_jobs;
     const int      nj = (int)(j1 - j0);
     // Four consecutive plain 8x8 blocks share one matrix-core tile: their residuals side by side in the LDS tile, one pair of MFMAs, four SATDs
     uint32_t quad8 = 0; // bit g: jobs 4g .. 4g + 3 of the wave
@@ -494,7 +507,7 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         u64      sse;
         block_stats_job<Pix>(p, L, j0 + k, lane, !((quad8 >> (k >> 2)) & 1), sad, sum, sse);
         if (lane == k) { my_sad = sad; my_sum = sum; my_sse = sse; }
-        __syncthreads(); // the LDS tile is reused by the next job
+        stats_wave_sync(); // the LDS tile is reused by the next job
     }
     // svt_psy_distortion{,_hbd}: one lane per 8x8 (or 4x4) tile, the tiles of the wave's jobs side by side
     u64 my_e = 0;
@@ -514,7 +527,7 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
         static_assert(kJobsPerWave <= 16, "the prefix sum runs inside one DPP row");
         if (lane < kJobsPerWave) { tile0[lane + 1] = (uint32_t)incl; esum[lane] = 0; }
         if (lane == 0) tile0[0] = 0;
-        __syncthreads();
+        stats_wave_sync();
         const int total = (int)tile0[kJobsPerWave];
         for (int t = lane; t < total; t += 64) {
             int k = 0;
@@ -530,7 +543,7 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
             const int32_t b = psy_tile_energy<Pix>(ref.sub(ty * n, tx * n), n);
             atomicAdd(&esum[k], (uint32_t)(a > b ? a - b : b - a)); // a job's sum stays below 2^32: 256 tiles x 64 x 64 x 1023
         }
-        __syncthreads();
+        stats_wave_sync();
         const u64 e = lane < kJobsPerWave ? esum[lane] : 0;
         my_e = sizeof(Pix) == 1 ? e >> 1 : e << 2;
     }
@@ -550,7 +563,7 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
             const SvtHipBlockJob jb = p.d.jobs[j0 + 4 * g + q];
             quad_residual(static_cast<const Pix *>(p.d.src) + jb.src_offset + (size_t)r * p.d.src_stride + c, static_cast<const Pix *>(p.d.ref) + jb.ref_offset + (size_t)r * p.d.ref_stride + c,
                           &L.res[(8 * (q >> 1) + r) * kResPitch + 8 * (q & 1) + c]);
-            __syncthreads();
+            stats_wave_sync();
             int32_t y[4];
             had8x4_mfma(L, 0, 0, lane, had16_weights(lane), y);
             uint32_t sv = 0;
@@ -559,7 +572,7 @@ template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel
             // block (k0 / 8, r / 8) = (lane bit 5, lane bit 3): sum over the other four lane bits
             sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64); sv += __shfl_xor(sv, 16, 64);
             if ((lane & 23) == 0) p.d.satd[j0 + 4 * g + 2 * (lane >> 5) + ((lane >> 3) & 1)] = sv;
-            __syncthreads(); // the tile is rewritten by the next group
+            stats_wave_sync(); // the tile is rewritten by the next group
         }
 }
 
@@ -576,9 +589,8 @@ __device__ __forceinline__ uint32_t row16_sum_of_quads(uint32_t v) { // v unifor
 }
 // Without hadamard_path (the psy / facade batches): ONE wave per region, lane <-> one 8x8 block in Morton order (one psy tile per lane: every
 // lane busy in the tile transforms), 16x16 = quad, 32x32 = 16-lane row, 64x64 = the wave.
-template <typename Pix> __global__ void __launch_bounds__(64) block_stats_pyramid1_kernel(const StatsParams p) {
-    const int      lane = threadIdx.x;
-    const uint32_t reg = blockIdx.x, out0 = p.d.pyramid_out_base + SVT_HIP_PYRAMID_BLOCKS * reg;
+template <typename Pix> __device__ __forceinline__ void block_stats_pyramid1(const StatsParams &p, const uint32_t reg, const int lane) {
+    const uint32_t out0 = p.d.pyramid_out_base + SVT_HIP_PYRAMID_BLOCKS * reg;
     const SvtHipBlockJob jb = p.d.pyramids[reg];
     const Pix *src = static_cast<const Pix *>(p.d.src) + jb.src_offset, *ref = static_cast<const Pix *>(p.d.ref) + jb.ref_offset;
     // lane -> 8x8 block coordinates: bits x0 y0 x1 y1 x2 y2
@@ -629,10 +641,9 @@ struct PyrLds {
     int32_t  sum[4];
     u64      sse[4];
 };
-template <typename Pix> __global__ void __launch_bounds__(256) block_stats_pyramid_kernel(const StatsParams p) {
-    __shared__ PyrLds S;
+template <typename Pix> __device__ __forceinline__ void block_stats_pyramid4(const StatsParams &p, PyrLds &S, const uint32_t reg) {
     const int      lane = threadIdx.x & 63, q = threadIdx.x >> 6, qy = q >> 1, qx = q & 1;
-    const uint32_t reg = blockIdx.x, out0 = p.d.pyramid_out_base + SVT_HIP_PYRAMID_BLOCKS * reg;
+    const uint32_t out0 = p.d.pyramid_out_base + SVT_HIP_PYRAMID_BLOCKS * reg;
     const SvtHipBlockJob jb = p.d.pyramids[reg];
     const Pix *src = static_cast<const Pix *>(p.d.src) + jb.src_offset + (size_t)(32 * qy) * p.d.src_stride + 32 * qx;
     const Pix *ref = static_cast<const Pix *>(p.d.ref) + jb.ref_offset + (size_t)(32 * qy) * p.d.ref_stride + 32 * qx;
@@ -726,6 +737,29 @@ template <typename Pix> __global__ void __launch_bounds__(256) block_stats_pyram
         for (int k = 0; k < 4; k++) { sse += S.sse[k]; e += (u64)S.e_lo[k] + ((u64)S.e_hi[k] << 16); sd += S.sad[k]; sm += S.sum[k]; st += S.satd[k]; }
         emit(out0, 64, sd, sm, sse, e);
         if (p.d.satd) p.d.satd[out0] = st; // hadamard_path_c: a 64x64 block is four 32x32 tiles
+    }
+}
+
+// One launch per batch: the regions first, the flat jobs behind them (two launches on one stream would run one after the other, and a batch of one
+// picture is a few microseconds of work per kernel).
+// without hadamard_path: a wave per workgroup -- region `blockIdx.x`, or wave (blockIdx.x - n_pyramids) of the flat list
+template <typename Pix> __global__ void __launch_bounds__(64) block_stats_kernel(const StatsParams p) {
+    __shared__ FlatLds F;
+    if (blockIdx.x < p.n_front) block_stats_pyramid1<Pix>(p, blockIdx.x, threadIdx.x);
+    else block_stats_flat<Pix>(p, F, blockIdx.x - p.n_front, threadIdx.x);
+}
+// with hadamard_path: four waves per workgroup -- region `blockIdx.x`, or four waves of the flat list (a workgroup takes one branch as a whole:
+// the region's barrier is reached by all of its waves)
+union Stats4Lds {
+    PyrLds  S;
+    FlatLds F[4];
+};
+template <typename Pix> __global__ void __launch_bounds__(256) block_stats4_kernel(const StatsParams p) {
+    __shared__ Stats4Lds U;
+    if (blockIdx.x < p.n_front) block_stats_pyramid4<Pix>(p, U.S, blockIdx.x);
+    else {
+        const uint32_t wave = (blockIdx.x - p.n_front) * 4 + (threadIdx.x >> 6);
+        if (wave * kJobsPerWave < p.d.n_jobs) block_stats_flat<Pix>(p, U.F[threadIdx.x >> 6], wave, threadIdx.x & 63);
     }
 }
 
@@ -861,16 +895,12 @@ int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d)
     hipSetDevice(ctx->device);
     StatsParams p;
     p.d = *d;
-    const uint32_t grid = (d->n_jobs + kJobsPerWave - 1) / kJobsPerWave;
-    if (grid) {
-        if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_kernel<uint8_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
-        else hipLaunchKernelGGL(block_stats_kernel<uint16_t>, dim3(grid), dim3(64), 0, ctx->stream, p);
-    }
-    if (d->n_pyramids) {
-        if (d->satd) hipLaunchKernelGGL(block_stats_pyramid_kernel<uint8_t>, dim3(d->n_pyramids), dim3(256), 0, ctx->stream, p); // (8-bit planes: checked above)
-        else if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_pyramid1_kernel<uint8_t>, dim3(d->n_pyramids), dim3(64), 0, ctx->stream, p);
-        else hipLaunchKernelGGL(block_stats_pyramid1_kernel<uint16_t>, dim3(d->n_pyramids), dim3(64), 0, ctx->stream, p);
-    }
+    const uint32_t flat = (d->n_jobs + kJobsPerWave - 1) / kJobsPerWave; // waves of the flat list
+    p.n_front = d->n_pyramids;
+    if (d->satd && d->n_pyramids) // (8-bit planes: checked above)
+        hipLaunchKernelGGL(block_stats4_kernel<uint8_t>, dim3(d->n_pyramids + (flat + 3) / 4), dim3(256), 0, ctx->stream, p);
+    else if (d->bit_depth == 8) hipLaunchKernelGGL(block_stats_kernel<uint8_t>, dim3(d->n_pyramids + flat), dim3(64), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(block_stats_kernel<uint16_t>, dim3(d->n_pyramids + flat), dim3(64), 0, ctx->stream, p);
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }
