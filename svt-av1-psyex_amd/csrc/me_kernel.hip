@@ -216,6 +216,7 @@ __device__ __forceinline__ u64 wave_sum64(u64 v) {
 __host__ __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // svt_aom_get_scaled_picture_distance, motion_estimation.c:1239-1243
@@ -736,13 +737,13 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
 // (piece n = owner n / NV, part n % NV: the NV lanes of a row side by side in one or two lines), hands them over through the arena, and
 // every owner reads its row back with NV ds_read_b128 (lane stride NV x 16 bytes, NV odd: conflict-free).  The next step's pieces are on
 // their way while the current one is evaluated.  `wp` = the owner's first window row (idle lanes: rows <= 0), `wstep` uniform.
-template <int NDW, int DEPTH>
+// (Two steps in flight were measured no faster: 0.387 vs 0.390 ms for the level-2 kernel.)
+template <int NDW>
 __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, int sp, int srs, const uint8_t *wp, long long wstep, int e0, int rows, int rows_max, uint32_t out[8]) {
     constexpr int NV = (NDW + 2 + 3) / 4, kRowsPerFlush = 64 / NDW;
     static_assert(NV & 1, "owners read their pieces back without bank conflicts");
-    static_assert(DEPTH == 1 || DEPTH == 2, "steps in flight");
     const int lane = threadIdx.x;
-    const uint8_t *pp[NV]; // where this lane fetches piece (lane + 64 k) of the next step to request
+    const uint8_t *pp[NV]; // where this lane fetches piece (lane + 64 k) of a step
     int            pn[NV]; // steps its owner makes
 #pragma unroll
     for (int k = 0; k < NV; k++) {
@@ -752,26 +753,19 @@ __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, 
         pn[k] = __shfl(rows, owner, 64);
     }
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    V4U v[DEPTH][NV];
-    auto request = [&](V4U (&r)[NV], int step) { // the pieces of `step` (requests are made in step order: pp walks along)
+    V4U v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = pn[k] > 0 ? *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k])) : V4U{0, 0, 0, 0};
+    u64 acc0 = 0, acc1 = 0;
+    for (int t = 0; t < rows_max; t++) { // uniform
+#pragma unroll
+        for (int k = 0; k < NV; k++) *reinterpret_cast<V4U *>(arena + 16 * (lane + 64 * k)) = v[k];
+        wave_sync();
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            if (step < pn[k]) r[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k]));
             pp[k] += wstep;
+            if (t + 1 < pn[k]) v[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k]));
         }
-    };
-#pragma unroll
-    for (int dpt = 0; dpt < DEPTH; dpt++) {
-#pragma unroll
-        for (int k = 0; k < NV; k++) v[dpt][k] = V4U{0, 0, 0, 0};
-        request(v[dpt], dpt);
-    }
-    u64 acc0 = 0, acc1 = 0;
-    auto step = [&](V4U (&r)[NV], int t) {
-#pragma unroll
-        for (int k = 0; k < NV; k++) *reinterpret_cast<V4U *>(arena + 16 * (lane + 64 * k)) = r[k];
-        wave_sync();
-        request(r, t + DEPTH);
         if (t < rows) {
             const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (e0 + t) * srs * sp);
             uint32_t sv[NDW], wv[4 * NV];
@@ -797,10 +791,6 @@ __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, 
             acc0 = acc1 = 0;
         }
         wave_sync(); // the arena is rewritten
-    };
-    for (int t = 0; t < rows_max; t += DEPTH) { // uniform
-        step(v[0], t);
-        if (DEPTH == 2 && t + 1 < rows_max) step(v[DEPTH - 1], t + 1);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = a[i];
@@ -820,7 +810,7 @@ __device__ __forceinline__ bool small_direct_ok(const St &st) {
     if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
     return ((w + 7) >> 3) * h * nreq <= kThreads; // octet items of one slice
 }
-template <int DEPTH = 1> __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
+__device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
     St       &st   = sh.st;
     const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
     // every search like the first one, few positions, whole-vector source rows
@@ -850,8 +840,8 @@ template <int DEPTH = 1> __device__ __forceinline__ bool run_small_searches_dire
         wp   = r.win + (long long)y * r.stride + (long long)e0 * wstep + 8 * g;
     }
     uint32_t s8[8];
-    if (bw == 64) direct_rows<16, DEPTH>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
-    else direct_rows<8, DEPTH>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    if (bw == 64) direct_rows<16>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    else direct_rows<8>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
     for (int p = lane; p < nreq * kNarrowMaxPos; p += kThreads) sad[p] = 0;
     wave_sync();
     if (mine) {
@@ -917,12 +907,6 @@ __device__ __forceinline__ void push_hme_req(St &st, CParams &p, int level, CPla
 // Integer search: 85 square PUs per position
 // ---------------------------------------------------------------------------------------------
 
-// lane -> 8x8 block coordinates in the reference's PU order (quad-tree / Morton): bits x0 y0 x1 y1 x2 y2
-__device__ __forceinline__ void lane_to_blk(int lane, int &bx, int &by) {
-    bx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
-    by = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
-}
-
 __device__ __forceinline__ uint32_t dpp_quad_sum(uint32_t v) {
     // sum over the 4 lanes of a quad, result in all 4 lanes
     uint32_t t = v + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
@@ -934,23 +918,6 @@ __device__ __forceinline__ uint32_t sum16_of_quads(uint32_t v) {
     uint32_t t = v + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true);
     return t + (uint32_t)__builtin_amdgcn_mov_dpp((int)t, 0x140 /* row_mirror */, 0xF, 0xF, true);
 }
-
-#ifdef SVT_ME_V64_BPERMUTE
-constexpr int kLane64 = 0; // the lane that keeps the 64x64 running best
-__device__ __forceinline__ uint32_t sum64_of_rows(uint32_t v) {
-    // v uniform inside each 16-lane row; returns the sum of the 4 rows in all lanes
-    uint32_t t = v + (uint32_t)__shfl_xor((int)v, 16, 64);
-    return t + (uint32_t)__shfl_xor((int)t, 32, 64);
-}
-#else
-constexpr int kLane64 = 63;
-__device__ __forceinline__ uint32_t sum64_of_rows(uint32_t v) {
-    // v uniform inside each 16-lane row; the sum of the 4 rows, valid in the LAST row (lanes 48..63) only: two DPP row broadcasts
-    // (lane 15 of a row into the next row, then lane 31 into rows 2 and 3) instead of two cross-lane permutes through the LDS unit
-    const uint32_t t = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
-    return t + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
-}
-#endif
 
 __device__ __forceinline__ void upd(u64 &best, uint32_t sad, uint32_t ord) {
     const u64 k = ((u64)sad << 32) | ord;
@@ -971,21 +938,21 @@ __device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const uint
 
 // the wave: integer search for the refs in list[0 .. count).  `merge` semantics follow the reference: strict
 // `<` against what is already in best_sad (initial MAX_SAD_VALUE, or the probe's result).
+//
+// Lane <-> (row group g = lane / 16, 16x16 PU pu = lane % 16 in quad-tree order): a step evaluates FOUR search rows (one per group) x four
+// columns (one v_qsad_pk_u16_u8 quad).  A lane adds up the four 8x8 SADs of its 16x16 block itself (plain adds), the 32x32 sums are quad
+// sums, the 64x64 sums 16-lane row sums (DPP): 3 x 4 adds + 4 DPP per position instead of 6 DPP per position and lane.  The running bests
+// are packed keys (sad << 12 | position inside the tile, raster order): one v_lshl_or + one v_min per PU size and position -- the first
+// minimum in raster order wins, like the reference's strict `<` -- against three instructions for a compare and two selects.  Measured on
+// the bench launch (one-wave-per-8x8 layout before): ~20 VALU instructions per position and wave -> ~8.
+constexpr int kMeOrdBits = 12; // positions of one tile: at most 4096 (the tile sizing below); 64x64 SADs stay below 2^20
 __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count, uint32_t *bsad, uint32_t *bmv, int r0n) {
     const int lane = threadIdx.x;
     const int sub  = (p.cfg.me_search_method == 0);
-    const int nrow = sub ? 4 : 8, rstep = sub ? 2 : 1;
-    int       bx, by;
-    lane_to_blk(lane, bx, by);
-    // this lane's 8x8 source block (every other row when sub-sampling): 2 dwords per row, in registers
-    uint32_t s[8][2];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int row = (by * 8 + (k < nrow ? k * rstep : 0)) >> sh.cshift;
-        const uint32_t *sp = reinterpret_cast<const uint32_t *>(&LDS(sh.src64)[row * kSrc64Pitch + bx * 8]);
-        s[k][0] = sp[0];
-        s[k][1] = sp[1];
-    }
+    const int nrow = sub ? 4 : 8, rstep = sub ? 2 : 1; // rows of an 8x8 block that are compared
+    const int g = lane >> 4, pu = lane & 15;
+    const int bx = (pu & 1) | ((pu >> 1) & 2), by = ((pu >> 1) & 1) | ((pu >> 2) & 2); // the 16x16 block: bits x0 y0 x1 y1
+    const uint8_t *srow = &LDS(sh.src64)[bx * 16]; // this lane's source rows: row r of the 64x64 block at ((r >> cshift) * kSrc64Pitch)
     for (int mi = 0; mi < count; mi++) {
         MeReq m;
         { // uniform: through SGPRs
@@ -995,20 +962,19 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
             m.li = (uint8_t)uni(mm.li); m.ri = (uint8_t)uni(mm.ri); m.probe = 0; m.pad = 0;
             m.min_x = (int16_t)uni((uint32_t)mm.min_x); m.max_x = (int16_t)uni((uint32_t)mm.max_x); m.min_y = (int16_t)uni((uint32_t)mm.min_y); m.max_y = (int16_t)uni((uint32_t)mm.max_y);
         }
-        u64 b8 = ~0ull, b16 = ~0ull, b32 = ~0ull, b64 = ~0ull;
-        // tile the search area by rows (and columns) so that the window fits the arena
+        u64 b8[4] = {~0ull, ~0ull, ~0ull, ~0ull}, b16 = ~0ull, b32 = ~0ull, b64 = ~0ull; // (sad << 32 | position in the search area), per PU of this lane
+        // tile the search area by rows (and columns) so that the window fits the arena and a tile's positions the keys
         const int W = m.sa_w, H = m.sa_h;
         int       tw = W, th = H;
         auto me_pitch = [](int shift, int ww) { return ((shift + ww - 1 + 64 + 15) & ~15) + 16; };
         auto wbytes = [&](int ww, int hh) { return (uint32_t)me_pitch(0, ww) * (uint32_t)(hh - 1 + 64); };
-        while (th > 1 && wbytes(tw, th) > (uint32_t)kWinBytes) th = (th + 1) >> 1;
-        while (tw > 8 && wbytes(tw, th) > (uint32_t)kWinBytes) tw = ((tw >> 1) + 7) & ~7;
+        while (th > 1 && (wbytes(tw, th) > (uint32_t)kWinBytes || tw * th > (1 << kMeOrdBits))) th = (th + 1) >> 1;
+        while (tw > 8 && (wbytes(tw, th) > (uint32_t)kWinBytes || tw * th > (1 << kMeOrdBits))) tw = ((tw >> 1) + 7) & ~7;
         for (int y0 = 0; y0 < H; y0 += th)
             for (int x0 = 0; x0 < W; x0 += tw) {
                 const int w = imin(tw, W - x0), h = imin(th, H - y0);
                 const uint8_t *gwin  = m.pix0 + (m.ox + x0) + (long long)(m.oy + y0) * m.stride;
-                const int      shift = 0; // the rows are fetched with unaligned 16-byte loads: position x0 sits on LDS byte 0 of its row
-                const int pitch = me_pitch(shift, w); // 16-byte rows; same formula as the tile sizing above
+                const int pitch = me_pitch(0, w); // 16-byte rows (fetched with unaligned 16-byte loads: position x0 sits on LDS byte 0 of its row)
                 const int rows        = h - 1 + 64;
                 const int vec_per_row = pitch >> 4;
                 const float vpr_rcp   = rcp_of((uint32_t)vec_per_row);
@@ -1018,7 +984,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                 // -- uniform test -- is staged sample by sample with coordinates clamped to the plane's edge instead.
                 // (The vector loads of the fast path run up to 15 bytes before and 31 bytes behind the samples they need: the planes
                 // carry that much slack around every row, pictures.hip.)
-                const int wx0 = m.ox + x0 - shift, wy0 = m.oy + y0;
+                const int wx0 = m.ox + x0, wy0 = m.oy + y0;
                 if (m.ox + x0 >= m.min_x && m.ox + x0 + w - 1 + 63 <= m.max_x && wy0 >= m.min_y && wy0 + rows - 1 <= m.max_y) {
                     const int nvec = vec_per_row * rows;
                     for (int base = lane; base < nvec; base += 4 * kThreads) { // four independent loads in flight per lane
@@ -1038,47 +1004,68 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                     stage_clamped(LDS(sh.win), m.pix0, m.stride, m.min_x, m.max_x, m.min_y, m.max_y, wx0, wy0, pitch, rows);
                 }
                 wave_sync();
-                const int ng = ((shift & 3) + w + 3) >> 2;
-                // inside a tile the positions come in raster order: a strict `<` on the SAD keeps the first minimum; tiles merge by (sad, position)
-                uint32_t t8 = ~0u, t16 = ~0u, t32 = ~0u, t64 = ~0u, o8 = ~0u, o16 = ~0u, o32 = ~0u, o64 = ~0u;
-                for (int q = 0; q < ng * h; q++) { // uniform: the wave <-> one quad of positions
-                    const int y = q / ng, g = q - y * ng;
-                    const int col0 = (shift & ~3) + 4 * g, xq = col0 - shift;
-                    const uint8_t *wp = &LDS(sh.win)[(y + by * 8) * pitch + col0 + bx * 8];
-                    u64 acc = 0;
+                const int ng = (w + 3) >> 2;
+                uint32_t k8[4] = {~0u, ~0u, ~0u, ~0u}, k16 = ~0u, k32 = ~0u, k64 = ~0u; // running bests of the tile: sad << 12 | y * w + x
+                const int kshift = kMeOrdBits + sub; // (a sub-sampled SAD counts twice)
+                for (int y = 0; y < h; y += 4) { // uniform: four search rows per step, one per lane group
+                    const bool live = y + g < h;
+                    const int  yy   = live ? y + g : h - 1; // (a dead group reads rows of the tile, its sums go nowhere)
+                    const uint8_t *wrow = &LDS(sh.win)[(yy + by * 16) * pitch + bx * 16];
+                    const uint32_t ord0 = (uint32_t)(yy * w);
+                    for (int gq = 0; gq < ng; gq++) { // uniform: a quad of columns
+                        const uint8_t *wp = wrow + 4 * gq;
+                        u64 acc[4] = {0, 0, 0, 0}; // the block's four 8x8 SADs (x0 y0 order), four positions each
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        if (k < nrow) {
-                            const uint32_t *wr = reinterpret_cast<const uint32_t *>(wp + k * rstep * pitch);
-                            const uint32_t d0 = wr[0], d1 = wr[1], d2 = wr[2];
-                            acc = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d1 << 32) | d0, s[k][0], acc);
-                            acc = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d2 << 32) | d1, s[k][1], acc);
-                        }
-                    }
+                        for (int half = 0; half < 2; half++) // the upper / lower pair of 8x8 blocks
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int x = xq + i;
-                        uint32_t  v8 = (uint32_t)((acc >> (16 * i)) & 0xFFFF);
-                        if (sub) v8 <<= 1;
-                        const uint32_t v16 = dpp_quad_sum(v8);
-                        const uint32_t v32 = sum16_of_quads(v16);
-                        const uint32_t v64 = sum64_of_rows(v32);
-                        if (x >= 0 && x < w) { // wave-uniform
-                            const uint32_t ord = (uint32_t)((y0 + y) * W + (x0 + x));
-                            if (v8 < t8) { t8 = v8; o8 = ord; }
-                            if (v16 < t16) { t16 = v16; o16 = ord; }
-                            if (v32 < t32) { t32 = v32; o32 = ord; }
-                            if (v64 < t64) { t64 = v64; o64 = ord; }
+                            for (int k = 0; k < 8; k++) {
+                                if (k < nrow) { // uniform
+                                    const int r = 8 * half + k * rstep; // row of the 16x16 block
+                                    const uint32_t *wr = reinterpret_cast<const uint32_t *>(wp + r * pitch);
+                                    const uint32_t d0 = wr[0], d1 = wr[1], d2 = wr[2], d3 = wr[3], d4 = wr[4];
+                                    const uint4 sv = *reinterpret_cast<const uint4 *>(srow + ((by * 16 + r) >> sh.cshift) * kSrc64Pitch);
+                                    acc[2 * half] = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d1 << 32) | d0, sv.x, acc[2 * half]);
+                                    acc[2 * half] = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d2 << 32) | d1, sv.y, acc[2 * half]);
+                                    acc[2 * half + 1] = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d3 << 32) | d2, sv.z, acc[2 * half + 1]);
+                                    acc[2 * half + 1] = __builtin_amdgcn_qsad_pk_u16_u8(((u64)d4 << 32) | d3, sv.w, acc[2 * half + 1]);
+                                }
+                            }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int x = 4 * gq + i;
+                            uint32_t v8[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v8[j] = (uint32_t)((acc[j] >> (16 * i)) & 0xFFFF);
+                            const uint32_t v16 = (v8[0] + v8[1]) + (v8[2] + v8[3]);
+                            const uint32_t v32 = dpp_quad_sum(v16);
+                            const uint32_t v64 = sum16_of_quads(v32);
+                            if (x < w && live) { // x: wave-uniform; live: whole 16-lane rows (the DPP sums above never leave a row)
+                                const uint32_t ord = ord0 + (uint32_t)x;
+#pragma unroll
+                                for (int j = 0; j < 4; j++) k8[j] = umin32(k8[j], (v8[j] << kshift) | ord);
+                                k16 = umin32(k16, (v16 << kshift) | ord);
+                                k32 = umin32(k32, (v32 << kshift) | ord);
+                                k64 = umin32(k64, (v64 << kshift) | ord);
+                            }
                         }
                     }
                 }
-                if (t8 != ~0u) upd(b8, t8, o8);
-                if (t16 != ~0u) upd(b16, t16, o16);
-                if (t32 != ~0u) upd(b32, t32, o32);
-                if (t64 != ~0u) upd(b64, t64, o64);
+                // the four row groups meet; tiles merge by (sad, position in the search area)
+                const float w_rcp = rcp_of((uint32_t)w);
+                auto fold = [&](u64 &best, uint32_t k) {
+                    k = umin32(k, (uint32_t)__shfl_xor((int)k, 16, 64));
+                    k = umin32(k, (uint32_t)__shfl_xor((int)k, 32, 64));
+                    if (k != ~0u) {
+                        const uint32_t ordl = k & ((1u << kMeOrdBits) - 1u), ty = div_by_rcp(ordl, w_rcp), tx = ordl - ty * (uint32_t)w;
+                        upd(best, k >> kMeOrdBits, (uint32_t)((y0 + (int)ty) * W + (x0 + (int)tx)));
+                    }
+                };
+#pragma unroll
+                for (int j = 0; j < 4; j++) fold(b8[j], k8[j]);
+                fold(b16, k16); fold(b32, k32); fold(b64, k64);
             }
         // the wave's bests -> this reference's rows of best_sad / best_mv, PU index in the reference's n_idx order: 0 = 64x64, 1..4, 5..20, 21..84.
-        // Each PU has one owner lane, so the compare-and-store below is race-free.
+        // Each PU has one owner lane (of group 0: after the fold every group holds the same keys), so the compare-and-store below is race-free.
         uint32_t *rs_ = bsad + ((m.li ? r0n : 0) + m.ri) * 85, *rm_ = bmv + ((m.li ? r0n : 0) + m.ri) * 85;
         auto merge = [&](int n, u64 k) {
             const uint32_t sad = (uint32_t)(k >> 32);
@@ -1089,10 +1076,13 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                 rm_[n] = ((uint32_t)(m.oy + yy) << 16) | (uint16_t)(m.ox + xx);
             }
         };
-        merge(21 + lane, b8);
-        if ((lane & 3) == 0) merge(5 + (lane >> 2), b16);
-        if ((lane & 15) == 0) merge(1 + (lane >> 4), b32);
-        if (lane == kLane64) merge(0, b64);
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) merge(21 + 4 * pu + j, b8[j]);
+            merge(5 + pu, b16);
+            if ((pu & 3) == 0) merge(1 + (pu >> 2), b32);
+            if (pu == 0) merge(0, b64);
+        }
         wave_sync();
     }
 }
@@ -1374,7 +1364,7 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
             wave_sync();
             if (st.nreq) { // uniform
                 if constexpr (me_is_staged_search(MODE)) run_searches(sh PROF_ARG);
-                else (void)run_small_searches_direct(sh PROF_ARG); // (two steps of rows in flight -- DEPTH 2, the kernel has the registers -- measured no faster: 0.387 vs 0.390 ms; the Mid kernel routed the block here because it qualifies)
+                else (void)run_small_searches_direct(sh PROF_ARG); // (the Mid kernel routed the block here because it qualifies)
             }
             wave_sync();
             u64 *keys = keys_of(gjob);
