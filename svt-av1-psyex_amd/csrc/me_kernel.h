@@ -144,8 +144,11 @@ struct MeDenseEntry {
 #ifndef SVT_HIP_ME_MID_WAVES_PER_SIMD
 #define SVT_HIP_ME_MID_WAVES_PER_SIMD 4
 #endif
+#ifndef SVT_HIP_ME_SEARCH_DEPTH
+#define SVT_HIP_ME_SEARCH_DEPTH 2 /* steps of window rows in flight in the search kernels' direct loop */
+#endif
 #ifndef SVT_HIP_ME_SEARCH_WAVES_PER_SIMD
-#define SVT_HIP_ME_SEARCH_WAVES_PER_SIMD 4
+#define SVT_HIP_ME_SEARCH_WAVES_PER_SIMD 3
 #endif
 #ifndef SVT_HIP_ME_TAIL_WAVES_PER_SIMD
 #define SVT_HIP_ME_TAIL_WAVES_PER_SIMD 2

@@ -737,13 +737,13 @@ __device__ __forceinline__ void run_searches(Shared &sh PROF_PARAM) {
 // (piece n = owner n / NV, part n % NV: the NV lanes of a row side by side in one or two lines), hands them over through the arena, and
 // every owner reads its row back with NV ds_read_b128 (lane stride NV x 16 bytes, NV odd: conflict-free).  The next step's pieces are on
 // their way while the current one is evaluated.  `wp` = the owner's first window row (idle lanes: rows <= 0), `wstep` uniform.
-// (Two steps in flight were measured no faster: 0.387 vs 0.390 ms for the level-2 kernel.)
-template <int NDW>
+template <int NDW, int DEPTH>
 __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, int sp, int srs, const uint8_t *wp, long long wstep, int e0, int rows, int rows_max, uint32_t out[8]) {
     constexpr int NV = (NDW + 2 + 3) / 4, kRowsPerFlush = 64 / NDW;
     static_assert(NV & 1, "owners read their pieces back without bank conflicts");
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "steps in flight");
     const int lane = threadIdx.x;
-    const uint8_t *pp[NV]; // where this lane fetches piece (lane + 64 k) of a step
+    const uint8_t *pp[NV]; // where this lane fetches piece (lane + 64 k) of the next step to request
     int            pn[NV]; // steps its owner makes
 #pragma unroll
     for (int k = 0; k < NV; k++) {
@@ -753,19 +753,26 @@ __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, 
         pn[k] = __shfl(rows, owner, 64);
     }
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    V4U v[NV];
-#pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = pn[k] > 0 ? *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k])) : V4U{0, 0, 0, 0};
-    u64 acc0 = 0, acc1 = 0;
-    for (int t = 0; t < rows_max; t++) { // uniform
-#pragma unroll
-        for (int k = 0; k < NV; k++) *reinterpret_cast<V4U *>(arena + 16 * (lane + 64 * k)) = v[k];
-        wave_sync();
+    V4U v[DEPTH][NV];
+    auto request = [&](V4U (&r)[NV], int step) { // the pieces of `step` (requests are made in step order: pp walks along)
 #pragma unroll
         for (int k = 0; k < NV; k++) {
+            if (step < pn[k]) r[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k]));
             pp[k] += wstep;
-            if (t + 1 < pn[k]) v[k] = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(pp[k]));
         }
+    };
+#pragma unroll
+    for (int dpt = 0; dpt < DEPTH; dpt++) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[dpt][k] = V4U{0, 0, 0, 0};
+        request(v[dpt], dpt);
+    }
+    u64 acc0 = 0, acc1 = 0;
+    auto step = [&](V4U (&r)[NV], int t) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) *reinterpret_cast<V4U *>(arena + 16 * (lane + 64 * k)) = r[k];
+        wave_sync();
+        request(r, t + DEPTH);
         if (t < rows) {
             const uint32_t *s = reinterpret_cast<const uint32_t *>(src + (e0 + t) * srs * sp);
             uint32_t sv[NDW], wv[4 * NV];
@@ -791,6 +798,11 @@ __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, 
             acc0 = acc1 = 0;
         }
         wave_sync(); // the arena is rewritten
+    };
+    for (int t = 0; t < rows_max; t += DEPTH) { // uniform
+        step(v[0], t);
+        if (DEPTH >= 2 && t + 1 < rows_max) step(v[DEPTH >= 2 ? 1 : 0], t + 1);
+        if (DEPTH >= 3 && t + 2 < rows_max) step(v[DEPTH >= 3 ? 2 : 0], t + 2);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = a[i];
@@ -810,7 +822,7 @@ __device__ __forceinline__ bool small_direct_ok(const St &st) {
     if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
     return ((w + 7) >> 3) * h * nreq <= kThreads; // octet items of one slice
 }
-__device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
+template <int DEPTH = 1> __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
     St       &st   = sh.st;
     const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
     // every search like the first one, few positions, whole-vector source rows
@@ -840,8 +852,10 @@ __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM)
         wp   = r.win + (long long)y * r.stride + (long long)e0 * wstep + 8 * g;
     }
     uint32_t s8[8];
-    if (bw == 64) direct_rows<16>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
-    else direct_rows<8>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    PROF(26);
+    if (bw == 64) direct_rows<16, DEPTH>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    else direct_rows<8, DEPTH>(LDS(sh.win), src, sp, srs, wp, wstep, e0, rows, rows_per, s8);
+    PROF(27);
     for (int p = lane; p < nreq * kNarrowMaxPos; p += kThreads) sad[p] = 0;
     wave_sync();
     if (mine) {
@@ -945,6 +959,7 @@ __device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const uint
 // are packed keys (sad << 12 | position inside the tile, raster order): one v_lshl_or + one v_min per PU size and position -- the first
 // minimum in raster order wins, like the reference's strict `<` -- against three instructions for a compare and two selects.  Measured on
 // the bench launch (one-wave-per-8x8 layout before): ~20 VALU instructions per position and wave -> ~8.
+constexpr int kMeInFlight = 4; // window vectors a lane has in flight while staging a tile (8 measured the same: 35 more spilled registers pay for the saved round trip)
 constexpr int kMeOrdBits = 12; // positions of one tile: at most 4096 (the tile sizing below); 64x64 SADs stay below 2^20
 __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count, uint32_t *bsad, uint32_t *bmv, int r0n) {
     const int lane = threadIdx.x;
@@ -987,18 +1002,23 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                 const int wx0 = m.ox + x0, wy0 = m.oy + y0;
                 if (m.ox + x0 >= m.min_x && m.ox + x0 + w - 1 + 63 <= m.max_x && wy0 >= m.min_y && wy0 + rows - 1 <= m.max_y) {
                     const int nvec = vec_per_row * rows;
-                    for (int base = lane; base < nvec; base += 4 * kThreads) { // four independent loads in flight per lane
-                        int  k[4];
-                        V4   v[4];
+                    // kMeInFlight independent loads per lane before the first is waited for
+                    for (int b0 = 0; b0 < nvec; b0 += kMeInFlight * kThreads) { // uniform
+                        const int base = b0 + lane;
+                        int  k[kMeInFlight];
+                        V4   v[kMeInFlight];
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            k[j] = imin(base + j * kThreads, nvec - 1);
-                            const int row = (int)div_by_rcp((uint32_t)k[j], vpr_rcp), c = k[j] - row * vec_per_row;
-                            const V4U q4 = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(gwin + (long long)row * m.stride + c * 16));
-                            v[j] = V4{q4.x, q4.y, q4.z, q4.w};
+                        for (int j = 0; j < kMeInFlight; j++) {
+                            if (b0 + j * kThreads < nvec) { // uniform: whole instructions beyond the window are skipped (lanes beyond it inside one repeat the last vector)
+                                k[j] = imin(base + j * kThreads, nvec - 1);
+                                const int row = (int)div_by_rcp((uint32_t)k[j], vpr_rcp), c = k[j] - row * vec_per_row;
+                                const V4U q4 = *reinterpret_cast<GV4U *>(reinterpret_cast<uintptr_t>(gwin + (long long)row * m.stride + c * 16));
+                                v[j] = V4{q4.x, q4.y, q4.z, q4.w};
+                            }
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; j++) *reinterpret_cast<V4 *>(&LDS(sh.win)[k[j] * 16]) = v[j];
+                        for (int j = 0; j < kMeInFlight; j++)
+                            if (b0 + j * kThreads < nvec) *reinterpret_cast<V4 *>(&LDS(sh.win)[k[j] * 16]) = v[j];
                     }
                 } else {
                     stage_clamped(LDS(sh.win), m.pix0, m.stride, m.min_x, m.max_x, m.min_y, m.max_y, wx0, wy0, pitch, rows);
@@ -1346,6 +1366,7 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
             // ---- search-only kernels: the block's requests in, their keys out ------------------------------------------------
             constexpr int lvl = (MODE == kMeS1 || MODE == kMeS1f) ? 1 : 2;
             const int ox = (int)(bxi * 64), oy = (int)(byi * 64), rstep = 1 << cshift;
+            PROF(24);
             import_reqs(gjob);
             if (tid == 0) st.nreq = *reinterpret_cast<const int *>(stage_base(gjob) + offsetof(St, nreq));
             if constexpr (lvl == 1) {
@@ -1362,9 +1383,10 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
                 }
             }
             wave_sync();
+            PROF(25);
             if (st.nreq) { // uniform
                 if constexpr (me_is_staged_search(MODE)) run_searches(sh PROF_ARG);
-                else (void)run_small_searches_direct(sh PROF_ARG); // (the Mid kernel routed the block here because it qualifies)
+                else (void)run_small_searches_direct<SVT_HIP_ME_SEARCH_DEPTH>(sh PROF_ARG); // (the Mid kernel routed the block here because it qualifies)
             }
             wave_sync();
             u64 *keys = keys_of(gjob);
@@ -2204,7 +2226,12 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
         wave_sync();
         PROF(16);
     }
-    PROF_FLUSH(hdr.queue_head + 16);
+#ifdef SVT_HIP_ME_PROFILE
+#ifndef SVT_HIP_ME_PROFILE_MODE
+#define SVT_HIP_ME_PROFILE_MODE 0 /* which kernel of the chain adds its phase sums (one table per diagnostic build) */
+#endif
+    if (MODE == SVT_HIP_ME_PROFILE_MODE) PROF_FLUSH(hdr.queue_head + 16);
+#endif
     if ((MODE == kMeFull || MODE == kMeMid1) && has_dense) { // counters of the context's diagnostics entry (svt_hip_me_dense_counters)
         const uint32_t h = wave_sum_u32(n_hit), m = wave_sum_u32(n_miss);
         if (tid == 0) {
