@@ -961,7 +961,7 @@ __device__ __attribute__((noinline)) void stage_clamped(uint8_t *win, const uint
 // the bench launch (one-wave-per-8x8 layout before): ~20 VALU instructions per position and wave -> ~8.
 constexpr int kMeInFlight = 4; // window vectors a lane has in flight while staging a tile (8 measured the same: 35 more spilled registers pay for the saved round trip)
 constexpr int kMeOrdBits = 12; // positions of one tile: at most 4096 (the tile sizing below); 64x64 SADs stay below 2^20
-__device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count, uint32_t *bsad, uint32_t *bmv, int r0n) {
+__device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const MeReq *list, int count, uint32_t *bsad, uint32_t *bmv, int r0n PROF_PARAM) {
     const int lane = threadIdx.x;
     const int sub  = (p.cfg.me_search_method == 0);
     const int nrow = sub ? 4 : 8, rstep = sub ? 2 : 1; // rows of an 8x8 block that are compared
@@ -1024,6 +1024,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                     stage_clamped(LDS(sh.win), m.pix0, m.stride, m.min_x, m.max_x, m.min_y, m.max_y, wx0, wy0, pitch, rows);
                 }
                 wave_sync();
+                PROF(46); // (diagnostic build: window staged)
                 const int ng = (w + 3) >> 2;
                 uint32_t k8[4] = {~0u, ~0u, ~0u, ~0u}, k16 = ~0u, k32 = ~0u, k64 = ~0u; // running bests of the tile: sad << 12 | y * w + x
                 const int kshift = kMeOrdBits + sub; // (a sub-sampled SAD counts twice)
@@ -1070,6 +1071,7 @@ __device__ __forceinline__ void run_me_searches(Shared &sh, CParams &p, const Me
                         }
                     }
                 }
+                PROF(47); // (diagnostic build: positions evaluated)
                 // the four row groups meet; tiles merge by (sad, position in the search area)
                 const float w_rcp = rcp_of((uint32_t)w);
                 auto fold = [&](u64 &best, uint32_t k) {
@@ -1972,7 +1974,7 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
                     const bool   probe = step == kProbe;
                     const MeReq *list  = probe ? st.me_probe : st.me;
                     const int    count = probe ? st.nprobe : st.nme;
-                    run_me_searches(sh, p, list, count, bsad, bmv, r0n);
+                    run_me_searches(sh, p, list, count, bsad, bmv, r0n PROF_ARG);
                 }
                 PROF(step == kProbe ? 3 : step == kMain ? 4 : 19);
             }

@@ -19,6 +19,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 rm -rf gpurun_out/${R}m
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES -d gpurun_out/${R}m -o bench --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${R}m.log 2>&1
 if [ -x tools/ubench/hadamard_mfma ]; then ./tools/ubench/hadamard_mfma > gpurun_out/hadamard_mfma.txt 2>&1 || true; fi
-if [ -f tools/_libprof7.so ]; then timeout -k 10 300 python tools/me_phase_profile.py > gpurun_out/me_phase.log 2>&1 || tail -5 gpurun_out/me_phase.log; fi
+if [ -f tools/_libprof7.so ]; then timeout -k 10 300 python tools/me_phase_profile.py 1 2 5 7 > gpurun_out/me_phase.log 2>&1 || tail -5 gpurun_out/me_phase.log; fi
 find gpurun_out/${R}s gpurun_out/${R}f gpurun_out/${R}w gpurun_out/${R}q -name "*.csv" | head -20
 echo verify-done

@@ -35,13 +35,14 @@ MODE = int(sys.argv[2]) if len(sys.argv) == 3 and sys.argv[1] == "--one" else -1
 # index -> phase (PROF(i) in csrc/me_kernel.hip)
 STAGES = ("zero-MV SADs", "pre-HME", "HME level 0", "HME level 1", "HME level 2", "check-00")
 PHASES = [
-    (0, "job fetch (queue atomic)"), (1, "block set-up: source 64x64 / 32x32 / 16x16 views into LDS"), (2, "stage preamble"),
+    (0, "job fetch (queue atomic)" if MODE == 0 else "end of the previous job (results out) + job fetch" if MODE != 1 else "everything behind the set-up (zero-MV / pre-HME / level-0 results folded, level-1 searches pushed, state out) + job fetch"), (1, "block set-up: source 64x64 / 32x32 / 16x16 views into LDS"), (2, "stage preamble"),
     (6, "control before zero-MV SADs"), (7, "control before pre-HME"), (8, "control before HME level 0"), (9, "control before HME level 1"),
     (10, "control before HME level 2"), (11, "control before check-00"), (12, "control before the 8x8-variance probe"), (20, "control before the integer search"),
 ] + [(24 + i, f"{n}: plan a round + issue its window loads" if MODE not in (2, 5) else ("search kernel: job flags read", "search kernel: requests + source view into LDS", "direct search: qualification, lane set-up", "direct search: row loop")[i] if i < 4 else "-") for i, n in enumerate(STAGES)] + [(32 + i, f"{n}: window registers -> LDS arena") for i, n in enumerate(STAGES)] + [
     (40 + i, f"{n}: rest of the evaluation (tile entry -> registers, arg-min across the wave, result)") for i, n in enumerate(STAGES)] + [
     (22, "all stages: plan the next round + issue its window loads (inside the evaluation phase)"), (30, "all stages: wide tiles, item loop (8 positions x whole block per lane)"),
-    (23, "all stages: small searches, item loop (8 positions x row slice per lane, LDS atomics)"), (19, "searches: tail"), (3, "8x8-variance probe (integer search at one position)"), (4, "integer search (staging, 85-PU SAD pyramid, bests)"),
+    (23, "all stages: small searches, item loop (8 positions x row slice per lane, LDS atomics)"), (19, "searches: tail"), (3, "8x8-variance probe: folding the bests, merge into best_sad / best_mv"), (4, "integer search: folding the bests, merge into best_sad / best_mv"),
+    (46, "integer search / probe: window staged (global -> registers -> LDS arena)"), (47, "integer search / probe: positions evaluated"),
     (5, "control after a stage (fold results, centres, early exits)"),
     (13, "reference pruning"), (14, "candidate lists"), (15, "distortions / variance outputs"), (16, "result rows stored"),
 ]
@@ -80,9 +81,14 @@ for i, name in PHASES:
     if col[i] >= 0.5:
         lines.append(f"{name:86s} {col[i]:12.0f} {100 * col[i] / tot:5.1f}")
 lines.append(f"{'total clocks per block (s_memtime)':86s} {tot:12.0f}")
-grp = {"control (serial, one lane)": (2, 6, 7, 8, 9, 10, 11, 12, 20, 5, 13), "set-up, outputs, fetch": (0, 1, 14, 15, 16), "probe + integer search": (3, 4)}
-grp.update({n + " (without the item loops)": (24 + i, 32 + i, 40 + i) for i, n in enumerate(STAGES)})
-grp["item loops (22, 30, 23)"] = (22, 30, 23)
+grp = {"control (serial, one lane)": (2, 6, 7, 8, 9, 10, 11, 12, 20, 5, 13), "set-up, outputs, fetch": (0, 1, 14, 15, 16), "probe + integer search": (3, 4, 46, 47)}
+if MODE in (2, 5):
+    grp = {"per-job prologue / epilogue (flags, requests, source view, lane set-up, arg-min, keys out; slots 0, 24, 25, 26, 23)": (0, 24, 25, 26, 23), "row loop (27)": (27,)}
+elif MODE == 1:
+    grp = {}  # (the kernel's straight-line stage flow has no marks behind the set-up: its time lands in the next job's fetch slot)
+else:
+    grp.update({n + " (without the item loops)": (24 + i, 32 + i, 40 + i) for i, n in enumerate(STAGES)})
+    grp["item loops (22, 30, 23)"] = (22, 30, 23)
 lines.append("")
 for g, idx in grp.items():
     v = sum(col[i] for i in idx)
