@@ -190,7 +190,7 @@ int   svt_hip_context_set_me_dense(SvtHipContext *ctx, int on);
 /* With the pre-pass on, the per-block pipeline can run STAGED: a chain of small kernels cut at its searches (control / level-1 searches / control /
  * level-2 searches / integer search and outputs), a block's state travelling through HBM between them -- each kernel has the register and
  * LDS budget of its own part only.  Blocks whose pre-HME / level-0 searches the pre-pass did not make go through the one-kernel form at the
- * end of the launch.  on = 0: never; 1 (default): launches of 4096 blocks and more (a small launch is latency-bound: one kernel serves it
+ * end of the launch.  on = 0: never; 1 (default): launches of 2048 blocks and more (a small launch is latency-bound: one kernel serves it
  * better than nine); 2: every launch.  SVT_HIP_ME_STAGED=0/1/2 sets it at context creation.  Results are identical either way. */
 int   svt_hip_context_set_me_staged(SvtHipContext *ctx, int on);
 /* Measurement aid: with timing on, an ME launch records events around each kernel of its chain, and svt_hip_me_launch_times returns the
@@ -201,7 +201,10 @@ int   svt_hip_context_set_me_staged(SvtHipContext *ctx, int on);
 int   svt_hip_context_set_me_timing(SvtHipContext *ctx, int on);
 int   svt_hip_me_launch_times(SvtHipContext *ctx, float ms[SVT_HIP_ME_CHAIN_KERNELS]);
 const char *svt_hip_me_chain_kernel_name(int i);
-/* Diagnostics: out[0] = searches the per-block kernel took from the pre-pass, out[1] = searches it made itself although the pre-pass was
+/* Diagnostics (off by default: the counters cost two device atomics per wave): with counting on, svt_hip_me_dense_counters returns what the
+ * launches since its last call did. */
+int   svt_hip_context_set_me_counting(SvtHipContext *ctx, int on);
+/* out[0] = searches the per-block kernel took from the pre-pass, out[1] = searches it made itself although the pre-pass was
  * on (edge blocks, configurations the pre-pass does not cover), since the last call; waits for the context's streams. */
 int   svt_hip_me_dense_counters(SvtHipContext *ctx, unsigned long long out[2]);
 

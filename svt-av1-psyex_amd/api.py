@@ -130,6 +130,10 @@ class Context:
         L.svt_hip_me_chain_kernel_name.restype = C.c_char_p
         return {L.svt_hip_me_chain_kernel_name(i).decode(): float(ms[i]) for i in range(9) if ms[i] > 0}
 
+    def set_me_counting(self, on):
+        """ME waves report what they took from the dense pre-pass (svt_hip_context_set_me_counting); off by default"""
+        self.check(lib().svt_hip_context_set_me_counting(self._h, 1 if on else 0), "svt_hip_context_set_me_counting")
+
     def me_dense_counters(self):
         """(searches taken from the dense pre-pass, searches the per-block kernel made itself) since the last call"""
         v = (C.c_ulonglong * 2)()

@@ -162,6 +162,7 @@ struct MeBatchHeader {
     uint32_t *queue_head; // SVT_HIP_ME_QUEUES counters, zeroed before launch
     MeDenseSlot *dense;   // results of the dense pre-pass, [job_base[n_pictures]][n_slot][SVT_HIP_ME_DENSE_KINDS]; null: no pre-pass
     uint32_t  n_dense_entries, n_dense_units;
+    uint32_t  count_dense; // the waves add their taken / own-search counts to the lane's counters (svt_hip_context_set_me_counting; two atomics per wave, serialised at the memory side: ~0.1 ms of a launch of 4096 waves)
     // staged launches (null otherwise): per job SVT_HIP_ME_STAGE_BYTES of travelling state, a flag word; three job lists (0: deferred to the
     // whole-pipeline kernel, 1 / 2: level-1 / level-2 searches in the staged form)
     uint8_t   *stage;

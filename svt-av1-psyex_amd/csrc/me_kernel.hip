@@ -166,7 +166,11 @@ struct LdsLayout { uint32_t src16, src32, src64, bsad, bmv, dense, win, total; }
 //   kMeTail  level-2 results, search centres, check-00, probe, integer search, pruning, candidates, outputs
 // A block's state (the head of St) and its search requests / results travel through HBM between them.
 constexpr int kMeFull = 0, kMeMid1 = 1, kMeS1 = 2, kMeS1f = 3, kMeMid2 = 4, kMeS2 = 5, kMeS2f = 6, kMeTail = 7;
-constexpr uint32_t kStagedMinJobs = 4096; // blocks of a launch from which the staged form is used
+#ifndef SVT_HIP_ME_LIST_WAVES_PER_CU
+#define SVT_HIP_ME_LIST_WAVES_PER_CU 2
+#endif
+constexpr uint32_t kListWavesPerCu = SVT_HIP_ME_LIST_WAVES_PER_CU;
+constexpr uint32_t kStagedMinJobs = 2048; // blocks of a launch from which the staged form is used (measured at 4,080 blocks -- a rank's share at 8 GPUs: 0.58 ms staged, 0.59 ms one-kernel; at 8,160: 0.75 / 0.80)
 __host__ __device__ constexpr bool me_is_search(int m) { return m == kMeS1 || m == kMeS1f || m == kMeS2 || m == kMeS2f; }
 __host__ __device__ constexpr bool me_is_staged_search(int m) { return m == kMeS1f || m == kMeS2f; }
 constexpr int kDirectWinBytes = 5120; // the direct searches' arena: a step's 64 x 5 window pieces, then the per-position sums [kMaxReq][kNarrowMaxPos] u32
@@ -2234,7 +2238,7 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
 #endif
     if (MODE == SVT_HIP_ME_PROFILE_MODE) PROF_FLUSH(hdr.queue_head + 16);
 #endif
-    if ((MODE == kMeFull || MODE == kMeMid1) && has_dense) { // counters of the context's diagnostics entry (svt_hip_me_dense_counters)
+    if ((MODE == kMeFull || MODE == kMeMid1) && has_dense && hdr.count_dense) { // counters of the context's diagnostics entry (svt_hip_me_dense_counters): uniform
         const uint32_t h = wave_sum_u32(n_hit), m = wave_sum_u32(n_miss);
         if (tid == 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(hdr.queue_head + SVT_HIP_ME_COUNTER_WORD), (unsigned long long)h);
@@ -2312,6 +2316,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
         SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->dense, 0xFF, need, lane->stream));
         hdr.dense = static_cast<MeDenseSlot *>(lane->dense);
         hdr.n_dense_entries = n_entries; hdr.n_dense_units = n_units;
+        hdr.count_dense = ctx->me_counting ? 1u : 0u;
     }
     // With a pre-pass the per-block pipeline runs STAGED: small kernels cut at its searches, a block's state travelling through HBM between them
     // (a launch of few blocks is bound by latency, not by throughput: the chain of nine short kernels costs it more than it gains)
@@ -2369,7 +2374,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
         if (per_cu > 4u * waves_per_simd) per_cu = 4u * waves_per_simd;
         if (ctx->me_waves_per_cu && per_cu > ctx->me_waves_per_cu) per_cu = ctx->me_waves_per_cu; // the caller leaves room for kernels of another stream
         uint32_t grid = (uint32_t)ctx->num_cus * per_cu;
-        if (flags & 1u) grid = (uint32_t)ctx->num_cus * 2u; // list kernels: their lists are short (edge blocks), a wave's first atomic is its exit test when they are empty
+        if ((flags & 1u) && grid > (uint32_t)ctx->num_cus * kListWavesPerCu) grid = (uint32_t)ctx->num_cus * kListWavesPerCu; // list kernels: their lists are short (edge blocks)
         if (grid > total) grid = total;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, lane->stream, d_hdr, d_par, flags);
     };
@@ -2393,6 +2398,12 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
 static const char *const kChainKernelNames[SVT_HIP_ME_CHAIN_KERNELS] = {"svt_hip_me_dense_kernel", "svt_hip_me_mid1_kernel", "svt_hip_me_s1_kernel",  "svt_hip_me_s1f_kernel", "svt_hip_me_mid2_kernel",
                                                                         "svt_hip_me_s2_kernel",    "svt_hip_me_s2f_kernel",  "svt_hip_me_tail_kernel", "svt_hip_me_b64_kernel"};
 extern "C" const char *svt_hip_me_chain_kernel_name(int i) { return i >= 0 && i < SVT_HIP_ME_CHAIN_KERNELS ? kChainKernelNames[i] : nullptr; }
+
+extern "C" int svt_hip_context_set_me_counting(SvtHipContext *ctx, int on) {
+    if (!ctx) return SVT_HIP_ERR_BAD_PARAM;
+    ctx->me_counting = on != 0;
+    return SVT_HIP_OK;
+}
 
 extern "C" int svt_hip_context_set_me_timing(SvtHipContext *ctx, int on) {
     if (!ctx) return SVT_HIP_ERR_BAD_PARAM;

@@ -49,6 +49,7 @@ struct SvtHipContext {
     int16_t    *iscan_dev;             // [19][3][1024] inverse scan orders (rd_kernel.hip), this device's copy
     bool        me_attr_set;           // hipFuncSetAttribute done for the ME kernel on this device
     int         me_staged;             // with a pre-pass, the per-block pipeline runs as a chain of small kernels: 0 never, 1 launches of many blocks, 2 always (svt_hip_context_set_me_staged)
+    bool        me_counting;           // ME waves report what they took from the dense pre-pass (svt_hip_context_set_me_counting)
     bool        me_timing;             // ME launches record events around their kernels (svt_hip_context_set_me_timing)
     bool        me_dense;              // the dense pre-HME / level-0 pre-pass runs ahead of the per-block ME kernel (svt_hip_context_set_me_dense)
     uint32_t    me_waves_per_cu;       // 0: as many persistent ME waves per CU as fit; else an upper limit (svt_hip_context_set_me_waves_per_cu)

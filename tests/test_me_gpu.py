@@ -246,6 +246,7 @@ def test_dense_prepass_is_used_and_changes_nothing(hip_ctx, me_form, kw):
     case = MeCase(**kw)
     want = case.run_cpu("oracle")
     try:
+        hip_ctx.set_me_counting(True)
         hip_ctx.set_me_dense(False)
         hip_ctx.me_dense_counters()
         off = case.run_hip(hip_ctx)
@@ -260,6 +261,7 @@ def test_dense_prepass_is_used_and_changes_nothing(hip_ctx, me_form, kw):
     finally:
         hip_ctx.set_me_dense(True)
         hip_ctx.set_me_staged(me_form)
+        hip_ctx.set_me_counting(False)
     assert not compare(want, off)
     assert not compare(want, on)
     assert not compare(want, staged)
@@ -277,8 +279,12 @@ def test_dense_prepass_skip_search_line_and_partial_octets(hip_ctx):
         cfg.me_early_exit_th = 0
     case = MeCase(416, 240, enc_mode=5, cfg_edit=edit, seed=31, kind="noise")
     want = case.run_cpu("oracle")
-    hip_ctx.me_dense_counters()
-    got = case.run_hip(hip_ctx)
-    taken, own = hip_ctx.me_dense_counters()
+    hip_ctx.set_me_counting(True)
+    try:
+        hip_ctx.me_dense_counters()
+        got = case.run_hip(hip_ctx)
+        taken, own = hip_ctx.me_dense_counters()
+    finally:
+        hip_ctx.set_me_counting(False)
     assert not compare(want, got)
     assert taken > 0
