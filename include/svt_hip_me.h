@@ -162,9 +162,10 @@ static inline uint32_t svt_hip_me_n_pu(uint8_t enable_me_16x16, uint8_t enable_m
  * THREADING CONTRACT.  One context per GPU is shared by all host threads, like the reference's kernel table is shared by its
  * ME and mode-decision threads (Globals/enc_handle.c:2265,2293; several pictures in flight, Codec/me_process.c:140-172):
  *   - every SYNCHRONOUS entry (host pointers in, results complete on return: svt_hip_me_picture,
- *     svt_hip_dg_detector_hme_level0, svt_hip_pa_picture_download, the pointer-level *_hip entries of svt_hip_leaf.h) may be
- *     called from any number of threads at once; each call runs on a stream, parameter block and result buffer of its own
- *     (at most 8 such calls execute concurrently, further callers wait);
+ *     svt_hip_dg_detector_hme_level0) may be called from any number of threads at once; each call runs on a stream, parameter
+ *     block and result buffer of its own (at most 8 such calls execute concurrently, further callers wait).  The pointer-level
+ *     *_hip entries of svt_hip_leaf.h are synchronous too but share ONE stream and lock (svt_hip_leaf.h), and
+ *     svt_hip_pa_picture_download copies on -- and waits for -- the context stream: it returns after everything enqueued there;
  *   - every ASYNCHRONOUS entry (device pointers: *_async, svt_hip_rd_batch, svt_hip_*_txfm_batch, svt_hip_block_stats_batch,
  *     svt_hip_fullpel_pred*, svt_hip_pa_picture_create*) enqueues on the ONE stream svt_hip_context_stream() returns.  They
  *     may be called from several threads too (enqueueing is serialised internally), but stream order is call order, and the

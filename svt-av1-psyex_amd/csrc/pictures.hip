@@ -308,6 +308,9 @@ SvtHipLaneGuard::SvtHipLaneGuard(SvtHipContext *ctx) : ctx_(ctx), lane_(nullptr)
 }
 
 SvtHipLaneGuard::~SvtHipLaneGuard() {
+    // A holder that leaves early (an error return between two enqueues) may leave work queued on the lane's stream: the next holder must not
+    // reuse -- or grow, i.e. free -- the lane's buffers under it.  After a normal call the stream is already idle and this returns at once.
+    if (lane_ && lane_->stream) hipStreamSynchronize(lane_->stream);
     {
         std::lock_guard<std::mutex> lk(ctx_->pool_mu);
         ctx_->lane_busy &= ~(1u << index_);
