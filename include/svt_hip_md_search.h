@@ -5,13 +5,16 @@
  *                               md_full_pel_search_large_lbd :1958-2027 = svt_pme_sad_loop_kernel :1905-1950), one job per call of it,
  *                               jobs chained ON THE DEVICE the way md_nsq_motion_search / md_sq_motion_search chain their calls (:2260-2375:
  *                               the candidate centres, the step-4 area, the +-2 and +-1 refinements each start from the previous best)
- *   svt_hip_md_subpel_batch   = svt_av1_find_best_sub_pixel_tree_pruned (Codec/mcomp.c:606-687) as md_subpel_search drives it
- *                               (product_coding_loop.c:2637-2750): the bilinear sub-pixel variance tree search (vfp->vf / vfp->svf,
- *                               Codec/av1me.c:29-172, C_DEFAULT/variance.c:28-75,256-318) with the MV-rate cost of Codec/mcomp.c:44-78.
+ *   svt_hip_md_subpel_batch   = the fractional_mv_step_fp md_subpel_search calls (product_coding_loop.c:2637-2750, :2723-2725):
+ *                               search_method 0: svt_av1_find_best_sub_pixel_tree_pruned (Codec/mcomp.c:606-687), the tree search on the bilinear
+ *                               sub-pixel variance (vfp->vf / vfp->svf, Codec/av1me.c:29-172, C_DEFAULT/variance.c:28-75,256-318);
+ *                               search_method 1: svt_av1_find_best_sub_pixel_tree (:688-777), the accurate search -- every candidate's error
+ *                               is vfp->vf of svt_aom_upsampled_pred (C_DEFAULT/variance.c:204-254: separable 2 / 4 / 8-tap interpolation,
+ *                               svt_aom_convolve8_horiz / _vert, Codec/convolve.c:244-301) -- with the round limits it derives from the MVP
+ *                               distance when its context says so (:702-722); both with the MV-rate cost of Codec/mcomp.c:44-78.
  *
- * Out of scope (said so in DESIGN.md): svt_av1_find_best_sub_pixel_tree (the accurate search: svt_aom_upsampled_pred needs the 8-tap
- * interpolation kernels), the SSD distortion type of md_full_pel_search (PSYEX adds get_svt_psy_full_dist with a double factor per position),
- * the 16-bit (hbd_md) forms.
+ * Out of scope (said so in DESIGN.md): the SSD distortion type of md_full_pel_search (PSYEX adds get_svt_psy_full_dist with a double factor
+ * per position), the 16-bit (hbd_md) forms.
  *
  * Asynchronous like the other batched entries: device pointers, enqueued on the context stream, one wave per job.
  */
@@ -70,7 +73,11 @@ typedef struct SvtHipFullpelBatchDesc {
 /* Jobs of one batch run concurrently: a job may only chain from a job of a batch enqueued earlier on the stream (same output arrays). */
 int svt_hip_md_fullpel_batch(SvtHipContext *ctx, const SvtHipFullpelBatchDesc *d);
 
-/* One svt_av1_find_best_sub_pixel_tree_pruned call */
+#define SVT_HIP_USE_2_TAPS 1
+#define SVT_HIP_USE_4_TAPS 2
+#define SVT_HIP_USE_8_TAPS 3
+
+/* One call of the sub-pel search function */
 typedef struct SvtHipSubpelJob {
     uint32_t src_offset;     /* ms_buffers->src->buf: the block's top-left sample in the source plane */
     uint32_t ref_offset;     /* ms_buffers->ref->buf: the co-located sample in the reference plane (MV (0, 0)) */
@@ -81,6 +88,10 @@ typedef struct SvtHipSubpelJob {
     SvtHipMv ref_mv;
     int16_t  col_min, col_max, row_min, row_max; /* SubpelMvLimits */
     int32_t  early_exit_th;  /* mv_cost_params.early_exit_th (1020 - (sq_size >> 2)) */
+    /* search_method 1 with mvp_th > 0 (the function's PD_PASS_1 / SPEL_ME branch, mcomp.c:702-722): ctx->best_fp_mvp_dist[list][ref] and
+     * ctx->mvp_array[list][ref][best_fp_mvp_idx] of the searched reference */
+    uint32_t best_mvp_dist;
+    SvtHipMv best_mvp;
 } SvtHipSubpelJob;
 
 typedef struct SvtHipSubpelBatchDesc {
@@ -91,6 +102,9 @@ typedef struct SvtHipSubpelBatchDesc {
     /* SUBPEL_MOTION_SEARCH_PARAMS (Codec/mcomp.h:85-104) */
     int32_t  allow_hp, forced_stop, iters_per_step, pred_variance_th, abs_th_mult, round_dev_th, skip_diag_refinement, bias_fp;
     int32_t  qp;                          /* pcs->picture_qp */
+    int32_t  search_method;               /* 0: svt_av1_find_best_sub_pixel_tree_pruned, 1: svt_av1_find_best_sub_pixel_tree (md_subpel_ctrls.subpel_search_method == SUBPEL_TREE) */
+    int32_t  subpel_search_type;          /* search_method 1: var_params.subpel_search_type -- SVT_HIP_USE_2_TAPS / _4_TAPS / _8_TAPS (definitions.h:728-733) */
+    int32_t  mvp_th, hp_mv_th;            /* search_method 1: ctx->md_subpel_me_ctrls.mvp_th / hp_mv_th when ctx->pd_pass == PD_PASS_1 and the stage is SPEL_ME, else 0 (branch off) */
     int32_t  mv_cost_type, error_per_bit;
     const int32_t *mvjcost;
     const int32_t *mvcost[2];
@@ -99,6 +113,7 @@ typedef struct SvtHipSubpelBatchDesc {
     uint32_t *besterr;                    /* [n_jobs]: the function's return value */
     int32_t  *distortion;                 /* [n_jobs] */
     uint32_t *sse;                        /* [n_jobs]: *sse1 (0 when no candidate improved on the start) */
+    uint32_t *center_err;                 /* optional, [n_jobs]: the error at the start MV = what the functions store into ctx->fp_me_dist[list][ref] */
 } SvtHipSubpelBatchDesc;
 
 int svt_hip_md_subpel_batch(SvtHipContext *ctx, const SvtHipSubpelBatchDesc *d);

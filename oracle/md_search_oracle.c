@@ -178,7 +178,7 @@ static void two_level_checks_fast(const Sp *s, SvtHipMv this_mv, SvtHipMv *best_
     }
 }
 
-static unsigned sub_pixel_tree_pruned(const Sp *s, SvtHipMv start_mv, SvtHipMv *bestmv, int *distortion, unsigned *sse1) {
+static unsigned sub_pixel_tree_pruned(const Sp *s, SvtHipMv start_mv, SvtHipMv *bestmv, int *distortion, unsigned *sse1, unsigned *center_err) {
     const SvtHipSubpelBatchDesc *d = s->d;
     int      hstep = 4; /* INIT_SUBPEL_STEP_SIZE */
     unsigned besterr, org_error;
@@ -189,6 +189,7 @@ static unsigned sub_pixel_tree_pruned(const Sp *s, SvtHipMv start_mv, SvtHipMv *
         *distortion = (int)variance_wxh(ref, (int)d->ref_stride, s->src, (int)d->src_stride, s->jb->width, s->jb->height, &sse);
         besterr     = (unsigned)*distortion + (unsigned)orc_mv_err_cost(bestmv->row, bestmv->col, &s->mp);
     }
+    *center_err = besterr;
     if (s->jb->early_neigh_check_exit) return besterr;
     const uint64_t th_normalizer = (uint64_t)(int64_t)(((s->jb->width * s->jb->height) >> 3) * (int)(uint8_t)d->abs_th_mult * (d->qp >> 1));
     if (besterr < th_normalizer) return besterr;
@@ -225,7 +226,147 @@ static unsigned sub_pixel_tree_pruned(const Sp *s, SvtHipMv start_mv, SvtHipMv *
     return besterr;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------------------- */
+/* svt_av1_find_best_sub_pixel_tree (mcomp.c:688-777): the accurate search                                                             */
+/* ---------------------------------------------------------------------------------------------------------------------------------- */
+/* rows 0, 2, .. 14 of av1_bilinear_filters / av1_sub_pel_filters_4 / av1_sub_pel_filters_8 (C_DEFAULT/variance.c:72-135): the kernels
+ * av1_get_interp_filter_subpel_kernel(filter, subpel_q3 << 1) selects for USE_2_TAPS / USE_4_TAPS / USE_8_TAPS (av1_get_filter, :191-201) */
+static const int16_t k_subpel_filters[3][8][8] = {
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 0, 112, 16, 0, 0, 0}, {0, 0, 0, 96, 32, 0, 0, 0}, {0, 0, 0, 80, 48, 0, 0, 0}, {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 48, 80, 0, 0, 0},
+     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, -8, 122, 18, -4, 0, 0}, {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -14, 94, 58, -10, 0, 0}, {0, 0, -12, 76, 76, -12, 0, 0},
+     {0, 0, -10, 58, 94, -14, 0, 0}, {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -4, 18, 122, -8, 0, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, -10, 122, 18, -4, 0, 0}, {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0}, {0, 2, -14, 76, 76, -14, 2, 0},
+     {0, 2, -12, 58, 94, -16, 2, 0}, {0, 2, -10, 38, 110, -14, 2, 0}, {0, 0, -4, 18, 122, -10, 2, 0}}};
+static uint8_t clip_pixel8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* svt_aom_upsampled_pred_c (C_DEFAULT/variance.c:204-254) = svt_aom_convolve8_horiz_c / _vert_c (Codec/convolve.c:244-301) at a fixed phase:
+ * 8 taps around the sample (offsets -3 .. +4), (sum + 64) >> 7, clipped to 8 bits after EACH pass (the intermediate is an 8-bit array) */
+static void upsampled_pred(uint8_t *pred, int w, int h, int sx, int sy, const uint8_t *ref, int ref_stride, int search_type) {
+    const int16_t *fx = k_subpel_filters[search_type - 1][sx], *fy = k_subpel_filters[search_type - 1][sy];
+    if (!sx && !sy) {
+        for (int y = 0; y < h; y++) memcpy(pred + y * w, ref + y * ref_stride, (size_t)w);
+    } else if (!sy) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int sum = 0;
+                for (int k = 0; k < 8; k++) sum += ref[y * ref_stride + x - 3 + k] * fx[k];
+                pred[y * w + x] = clip_pixel8((sum + 64) >> 7);
+            }
+    } else if (!sx) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int sum = 0;
+                for (int k = 0; k < 8; k++) sum += ref[(y - 3 + k) * ref_stride + x] * fy[k];
+                pred[y * w + x] = clip_pixel8((sum + 64) >> 7);
+            }
+    } else {
+        static uint8_t temp[(128 + 7) * 128]; /* rows -3 .. h + 3 of the horizontally filtered block (single-threaded test code) */
+        for (int y = 0; y < h + 7; y++)
+            for (int x = 0; x < w; x++) {
+                int sum = 0;
+                for (int k = 0; k < 8; k++) sum += ref[(y - 3) * ref_stride + x - 3 + k] * fx[k];
+                temp[y * 128 + x] = clip_pixel8((sum + 64) >> 7);
+            }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int sum = 0;
+                for (int k = 0; k < 8; k++) sum += temp[(y + k) * 128 + x] * fy[k];
+                pred[y * w + x] = clip_pixel8((sum + 64) >> 7);
+            }
+    }
+}
+
+/* svt_upsampled_pref_error (mcomp.c:106-143) */
+static int upsampled_pref_error(const Sp *s, SvtHipMv this_mv, unsigned *sse) {
+    static uint8_t pred[128 * 128];
+    const uint8_t *ref = s->ref + (this_mv.row >> 3) * (int)s->d->ref_stride + (this_mv.col >> 3);
+    upsampled_pred(pred, s->jb->width, s->jb->height, this_mv.col & 7, this_mv.row & 7, ref, (int)s->d->ref_stride, s->d->subpel_search_type);
+    return (int)variance_wxh(pred, s->jb->width, s->src, (int)s->d->src_stride, s->jb->width, s->jb->height, sse);
+}
+
+/* svt_check_better (mcomp.c:210-238) */
+static unsigned check_better(const Sp *s, SvtHipMv this_mv, SvtHipMv *best_mv, unsigned *besterr, unsigned *sse1, int *distortion, int *is_better) {
+    unsigned cost;
+    if (in_range(s, this_mv)) {
+        unsigned  sse;
+        const int thismse = upsampled_pref_error(s, this_mv, &sse);
+        cost = (unsigned)orc_mv_err_cost(this_mv.row, this_mv.col, &s->mp) + (unsigned)thismse;
+        int weight = 100;
+        if (s->d->bias_fp && best_mv->col % 8 == 0 && best_mv->row % 8 == 0) weight = s->d->bias_fp;
+        if ((((uint64_t)cost * (uint64_t)(int64_t)weight) / 100) < *besterr) {
+            *besterr = cost; *best_mv = this_mv; *distortion = thismse; *sse1 = sse; *is_better |= 1;
+        }
+    } else
+        cost = INT_MAX;
+    return cost;
+}
+
+static unsigned sub_pixel_tree(const Sp *s, SvtHipMv start_mv, SvtHipMv *bestmv, int *distortion, unsigned *sse1, unsigned *center_err) {
+    const SvtHipSubpelBatchDesc *d = s->d;
+    int      round = (3 /* FULL_PEL */ - d->forced_stop) < (3 - !d->allow_hp) ? (3 - d->forced_stop) : (3 - !d->allow_hp);
+    int      hstep = 4;
+    unsigned besterr;
+    *bestmv = start_mv;
+    { /* svt_upsampled_setup_center_error (mcomp.c:353-360) */
+        const uint8_t *ref = s->ref + (bestmv->row >> 3) * (int)d->ref_stride + (bestmv->col >> 3);
+        uint32_t       sse;
+        *distortion = (int)variance_wxh(ref, (int)d->ref_stride, s->src, (int)d->src_stride, s->jb->width, s->jb->height, &sse);
+        besterr     = (unsigned)*distortion + (unsigned)orc_mv_err_cost(bestmv->row, bestmv->col, &s->mp);
+    }
+    *center_err = besterr;
+    if (d->mvp_th > 0) { /* ctx != NULL, search_stage == SPEL_ME, pd_pass == PD_PASS_1 (:702-722) */
+        const int     mvp_err = (int)s->jb->best_mvp_dist + 1, me_err = (int)besterr + 1;
+        const int32_t deviation = ((me_err - mvp_err) * 100) / me_err;
+        if (deviation >= d->mvp_th)
+            round = 1;
+        else if (abs(bestmv->col - s->jb->best_mvp.col) > d->hp_mv_th || abs(bestmv->row - s->jb->best_mvp.row) > d->hp_mv_th)
+            round = round < 2 ? round : 2;
+    }
+    if (s->jb->early_neigh_check_exit) return besterr;
+    { /* variance of the full-pel prediction against the constant 128 (svt_aom_eb_av1_var_offs, stride 0) */
+        const uint8_t *ref = s->ref + (bestmv->row >> 3) * (int)d->ref_stride + (bestmv->col >> 3);
+        uint8_t        offs[128];
+        uint32_t       sse;
+        memset(offs, 128, sizeof(offs));
+        const unsigned var = variance_wxh(ref, (int)d->ref_stride, offs, 0, s->jb->width, s->jb->height, &sse);
+        const int block_var = (int)((var + ((1u << s->jb->log2_pels) >> 1)) >> s->jb->log2_pels);
+        if (block_var < d->pred_variance_th) return besterr;
+    }
+    const uint64_t th_normalizer = (uint64_t)(int64_t)(((s->jb->width * s->jb->height) >> 2) * (int)(uint8_t)d->abs_th_mult * (d->qp >> 1));
+    if (besterr < th_normalizer) return besterr;
+    if (!round) return besterr;
+    for (int iter = 0; iter < round; ++iter) {
+        const SvtHipMv c = *bestmv; /* iter_center_mv */
+        int dummy = 0;
+        /* svt_first_level_check (:260-287) */
+        const SvtHipMv left_mv = {c.row, (int16_t)(c.col - hstep)}, right_mv = {c.row, (int16_t)(c.col + hstep)}, top_mv = {(int16_t)(c.row - hstep), c.col},
+                       bottom_mv = {(int16_t)(c.row + hstep), c.col};
+        const unsigned left  = check_better(s, left_mv, bestmv, &besterr, sse1, distortion, &dummy);
+        const unsigned right = check_better(s, right_mv, bestmv, &besterr, sse1, distortion, &dummy);
+        const unsigned up    = check_better(s, top_mv, bestmv, &besterr, sse1, distortion, &dummy);
+        const unsigned down  = check_better(s, bottom_mv, bestmv, &besterr, sse1, distortion, &dummy);
+        SvtHipMv diag_step = {(int16_t)(up <= down ? -hstep : hstep), (int16_t)(left <= right ? -hstep : hstep)};
+        const SvtHipMv diag_mv = {(int16_t)(c.row + diag_step.row), (int16_t)(c.col + diag_step.col)};
+        check_better(s, diag_mv, bestmv, &besterr, sse1, distortion, &dummy);
+        if (!(c.row == bestmv->row && c.col == bestmv->col) && d->iters_per_step > 1) { /* svt_second_level_check_v2 (:292-350) */
+            if (c.row == bestmv->row) diag_step.row = (int16_t)-diag_step.row;
+            else if (c.col == bestmv->col) diag_step.col = (int16_t)-diag_step.col;
+            const SvtHipMv row_bias_mv = {(int16_t)(bestmv->row + diag_step.row), bestmv->col}, col_bias_mv = {bestmv->row, (int16_t)(bestmv->col + diag_step.col)},
+                           diag_bias_mv = {(int16_t)(bestmv->row + diag_step.row), (int16_t)(bestmv->col + diag_step.col)};
+            int has_better_mv = 0;
+            check_better(s, row_bias_mv, bestmv, &besterr, sse1, distortion, &has_better_mv);
+            check_better(s, col_bias_mv, bestmv, &besterr, sse1, distortion, &has_better_mv);
+            if (has_better_mv) check_better(s, diag_bias_mv, bestmv, &besterr, sse1, distortion, &has_better_mv);
+        }
+        hstep >>= 1;
+    }
+    return besterr;
+}
+
 int orc_md_subpel_batch(const SvtHipSubpelBatchDesc *d) {
+    if (d->search_method < 0 || d->search_method > 1) return 1;
+    if (d->search_method == 1 && (d->subpel_search_type < SVT_HIP_USE_2_TAPS || d->subpel_search_type > SVT_HIP_USE_8_TAPS)) return 1;
     for (uint32_t j = 0; j < d->n_jobs; j++) {
         Sp s;
         memset(&s, 0, sizeof(s));
@@ -236,7 +377,12 @@ int orc_md_subpel_batch(const SvtHipSubpelBatchDesc *d) {
         SvtHipMv best;
         int      dist = 0;
         unsigned sse1 = 0;
-        d->besterr[j]         = sub_pixel_tree_pruned(&s, s.jb->start_mv, &best, &dist, &sse1);
+        unsigned center = 0;
+        if (d->search_method == 1)
+            d->besterr[j] = sub_pixel_tree(&s, s.jb->start_mv, &best, &dist, &sse1, &center);
+        else
+            d->besterr[j] = sub_pixel_tree_pruned(&s, s.jb->start_mv, &best, &dist, &sse1, &center);
+        if (d->center_err) d->center_err[j] = center;
         d->best_mv[2 * j]     = best.row;
         d->best_mv[2 * j + 1] = best.col;
         d->distortion[j]      = dist;

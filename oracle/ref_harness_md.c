@@ -28,6 +28,8 @@ static void setup_variance_pointers(void) {
     VARP(4, 4) VARP(4, 8) VARP(4, 16) VARP(8, 4) VARP(8, 8) VARP(8, 16) VARP(8, 32) VARP(16, 4) VARP(16, 8) VARP(16, 16) VARP(16, 32) VARP(16, 64) VARP(32, 8)
     VARP(32, 16) VARP(32, 32) VARP(32, 64) VARP(64, 16) VARP(64, 32) VARP(64, 64) VARP(64, 128) VARP(128, 64) VARP(128, 128)
 #undef VARP
+    svt_aom_upsampled_pred = svt_aom_upsampled_pred_c; /* the accurate sub-pel search's predictor (C_DEFAULT/variance.c:204) ... */
+    svt_memcpy = svt_memcpy_c;                         /* ... which copies full-pel positions through this pointer (:216) */
     init_fn_ptr();
     done = 1;
 }
@@ -88,9 +90,17 @@ int ref_md_fullpel_batch(const SvtHipFullpelBatchDesc *d) {
     return 0;
 }
 
-/* svt_av1_find_best_sub_pixel_tree_pruned on the jobs of a SvtHipSubpelBatchDesc */
+/* svt_av1_find_best_sub_pixel_tree_pruned / svt_av1_find_best_sub_pixel_tree (search_method) on the jobs of a SvtHipSubpelBatchDesc.  The
+ * context argument is the reference's own ModeDecisionContext with the fields the functions read (the tree search's PD_PASS_1 branch,
+ * mcomp.c:702-722) and write (fp_me_dist) */
 int ref_md_subpel_batch(const SvtHipSubpelBatchDesc *d) {
     setup_variance_pointers();
+    ModeDecisionContext *ctx = (ModeDecisionContext *)calloc(1, sizeof(*ctx));
+    MacroBlockD          xd;
+    if (!ctx) return 2;
+    memset(&xd, 0, sizeof(xd));
+    ctx->pd_pass = d->mvp_th > 0 ? PD_PASS_1 : PD_PASS_0;
+    ctx->md_subpel_me_ctrls.mvp_th = (uint8_t)d->mvp_th; ctx->md_subpel_me_ctrls.hp_mv_th = d->hp_mv_th;
     for (uint32_t j = 0; j < d->n_jobs; j++) {
         const SvtHipSubpelJob      *jb = &d->jobs[j];
         SUBPEL_MOTION_SEARCH_PARAMS ms;
@@ -106,6 +116,10 @@ int ref_md_subpel_batch(const SvtHipSubpelBatchDesc *d) {
         ms.mv_cost_params.mvcost[0] = (const int *)d->mvcost[0]; ms.mv_cost_params.mvcost[1] = (const int *)d->mvcost[1];
         ms.mv_cost_params.error_per_bit = d->error_per_bit; ms.mv_cost_params.early_exit_th = jb->early_exit_th;
         ms.var_params.vfp = &svt_aom_mefn_ptr[bsize]; ms.var_params.w = jb->width; ms.var_params.h = jb->height; ms.var_params.bias_fp = d->bias_fp;
+        ms.var_params.subpel_search_type = (SUBPEL_SEARCH_TYPE)d->subpel_search_type;
+        ms.list_idx = 0; ms.ref_idx = 0;
+        ctx->best_fp_mvp_dist[0][0] = jb->best_mvp_dist; ctx->best_fp_mvp_idx[0][0] = 0;
+        ctx->mvp_array[0][0][0].row = jb->best_mvp.row; ctx->mvp_array[0][0][0].col = jb->best_mvp.col;
         struct svt_buf_2d src_b, ref_b;
         src_b.buf = (uint8_t *)d->src + jb->src_offset; src_b.stride = (int)d->src_stride; src_b.width = src_b.height = 0;
         ref_b.buf = (uint8_t *)d->ref + jb->ref_offset; ref_b.stride = (int)d->ref_stride; ref_b.width = ref_b.height = 0;
@@ -113,9 +127,12 @@ int ref_md_subpel_batch(const SvtHipSubpelBatchDesc *d) {
         MV           start = {jb->start_mv.row, jb->start_mv.col}, best = {0, 0};
         int          dist = 0;
         unsigned int sse1 = 0;
-        d->besterr[j] = (uint32_t)svt_av1_find_best_sub_pixel_tree_pruned(NULL, NULL, NULL, &ms, start, &best, &dist, &sse1, d->qp, bsize, jb->early_neigh_check_exit);
+        fractional_mv_step_fp *search = d->search_method == 1 ? svt_av1_find_best_sub_pixel_tree : svt_av1_find_best_sub_pixel_tree_pruned; /* product_coding_loop.c:2723-2725 */
+        d->besterr[j] = (uint32_t)search(ctx, &xd, NULL, &ms, start, &best, &dist, &sse1, d->qp, bsize, jb->early_neigh_check_exit);
         d->best_mv[2 * j] = best.row; d->best_mv[2 * j + 1] = best.col;
         d->distortion[j] = dist; d->sse[j] = sse1;
+        if (d->center_err) d->center_err[j] = ctx->fp_me_dist[0][0];
     }
+    free(ctx);
     return 0;
 }

@@ -230,12 +230,14 @@ class FullpelBatchDesc(C.Structure):
 
 SUBPEL_JOB_DTYPE = np.dtype([("src_offset", "<u4"), ("ref_offset", "<u4"), ("width", "u1"), ("height", "u1"), ("log2_pels", "u1"), ("early_neigh_check_exit", "u1"),
                              ("start_mv", "<i2", (2,)), ("ref_mv", "<i2", (2,)), ("col_min", "<i2"), ("col_max", "<i2"), ("row_min", "<i2"), ("row_max", "<i2"),
-                             ("early_exit_th", "<i4")], align=True)
+                             ("early_exit_th", "<i4"), ("best_mvp_dist", "<u4"), ("best_mvp", "<i2", (2,))], align=True)
+USE_2_TAPS, USE_4_TAPS, USE_8_TAPS = 1, 2, 3
 
 
 class SubpelBatchDesc(C.Structure):
     _fields_ = [("n_jobs", C.c_uint32), ("src_stride", C.c_uint32), ("ref_stride", C.c_uint32), ("src", C.c_void_p), ("ref", C.c_void_p), ("jobs", C.c_void_p),
                 ("allow_hp", C.c_int32), ("forced_stop", C.c_int32), ("iters_per_step", C.c_int32), ("pred_variance_th", C.c_int32), ("abs_th_mult", C.c_int32),
-                ("round_dev_th", C.c_int32), ("skip_diag_refinement", C.c_int32), ("bias_fp", C.c_int32), ("qp", C.c_int32), ("mv_cost_type", C.c_int32),
+                ("round_dev_th", C.c_int32), ("skip_diag_refinement", C.c_int32), ("bias_fp", C.c_int32), ("qp", C.c_int32), ("search_method", C.c_int32),
+                ("subpel_search_type", C.c_int32), ("mvp_th", C.c_int32), ("hp_mv_th", C.c_int32), ("mv_cost_type", C.c_int32),
                 ("error_per_bit", C.c_int32), ("mvjcost", C.c_void_p), ("mvcost", C.c_void_p * 2), ("best_mv", C.c_void_p), ("besterr", C.c_void_p),
-                ("distortion", C.c_void_p), ("sse", C.c_void_p)]
+                ("distortion", C.c_void_p), ("sse", C.c_void_p), ("center_err", C.c_void_p)]

@@ -7,7 +7,9 @@
 //     through v_sad_u8 / dot products straight from global memory (L1 / L2: the windows of a job are a few KB); the winner is the wave minimum
 //     of (cost << 32 | visiting order) against the incoming best with the reference's strict `<`.  Jobs chain on the device (centre and / or
 //     incoming best = an earlier job's outputs): the rounds of md_nsq_motion_search (:2260-2375) never come back to the host.
-//   md_subpel_kernel   = svt_av1_find_best_sub_pixel_tree_pruned (Codec/mcomp.c:606-687) with svt_estimated_pref_error (:147-167): the tree's
+//   md_subpel_kernel   = svt_av1_find_best_sub_pixel_tree (Codec/mcomp.c:688-777; search_method 1: every candidate's error is the variance of
+//     svt_aom_upsampled_pred -- separable 2 / 4 / 8-tap interpolation, recomputed per pixel) or
+//     svt_av1_find_best_sub_pixel_tree_pruned (Codec/mcomp.c:606-687) with svt_estimated_pref_error (:147-167): the tree's
 //     control flow is wave-uniform scalar code; each candidate's error = svt_aom_sub_pixel_variance{W}x{H}_c (C_DEFAULT/variance.c:28-75,
 //     308-318: two bilinear passes with 7-bit rounding, then sse - sum^2 / (w h)) with the block's pixels spread over the lanes.
 #include <hip/hip_runtime.h>
@@ -216,6 +218,67 @@ __device__ __forceinline__ uint32_t wave_sub_pixel_variance(const uint8_t *a, ui
     return sse - (uint32_t)(((i64)sum * sum) / n);
 }
 
+// rows 0, 2, .. 14 of av1_bilinear_filters / av1_sub_pel_filters_4 / av1_sub_pel_filters_8 (C_DEFAULT/variance.c:72-135): what
+// av1_get_interp_filter_subpel_kernel(av1_get_filter(subpel_search_type), subpel_q3 << 1) selects (:191-201, :219-222)
+__device__ const int8_t c_subpel_filters[3][8][8] = {
+    {{0, 0, 0, 127, 0, 0, 0, 0}, {0, 0, 0, 112, 16, 0, 0, 0}, {0, 0, 0, 96, 32, 0, 0, 0}, {0, 0, 0, 80, 48, 0, 0, 0}, {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 48, 80, 0, 0, 0},
+     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 16, 112, 0, 0, 0}},
+    {{0, 0, 0, 127, 0, 0, 0, 0}, {0, 0, -8, 122, 18, -4, 0, 0}, {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -14, 94, 58, -10, 0, 0}, {0, 0, -12, 76, 76, -12, 0, 0},
+     {0, 0, -10, 58, 94, -14, 0, 0}, {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -4, 18, 122, -8, 0, 0}},
+    {{0, 0, 0, 127, 0, 0, 0, 0}, {0, 2, -10, 122, 18, -4, 0, 0}, {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -16, 94, 58, -12, 2, 0}, {0, 2, -14, 76, 76, -14, 2, 0},
+     {0, 2, -12, 58, 94, -16, 2, 0}, {0, 2, -10, 38, 110, -14, 2, 0}, {0, 0, -4, 18, 122, -10, 2, 0}}};
+// (phase 0 -- weight 128, which an int8 cannot hold -- is never read: a pass with phase 0 is skipped, as in the reference)
+
+// the wave: variance of svt_aom_upsampled_pred (C_DEFAULT/variance.c:204-254; svt_aom_convolve8_horiz_c / _vert_c, Codec/convolve.c:244-301) of the
+// block at `a` (MV floor) at the 1/8 offsets (xo, yo) against `b`; lane <-> pixel.  8 taps at offsets -3 .. +4, (sum + 64) >> 7 and a clip to 8 bits
+// after EACH pass (the reference's intermediate is an 8-bit array): a 2-D position recomputes the eight horizontally filtered samples above and
+// below itself (64 multiply-adds per pixel; these searches are a few positions per block, nobody stages anything)
+__device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ uint32_t wave_upsampled_variance(const uint8_t *a, uint32_t as, int xo, int yo, int type, const uint8_t *b, uint32_t bs, int w, int h, uint32_t &sse_out) {
+    int fx[8], fy[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { fx[k] = c_subpel_filters[type - 1][xo][k]; fy[k] = c_subpel_filters[type - 1][yo][k]; }
+    int      sum = 0;
+    uint32_t sse = 0;
+    const int n = w * h, lw = 31 - __clz(w); // widths are powers of two
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const int y = i >> lw, x = i & (w - 1);
+        const uint8_t *r = a + (ptrdiff_t)y * (ptrdiff_t)as + x;
+        int v;
+        if (!xo && !yo)
+            v = r[0];
+        else if (!yo) {
+            int t = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t += (int)r[k - 3] * fx[k];
+            v = clip_u8((t + 64) >> 7);
+        } else if (!xo) {
+            int t = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t += (int)r[(ptrdiff_t)(k - 3) * (ptrdiff_t)as] * fy[k];
+            v = clip_u8((t + 64) >> 7);
+        } else {
+            int t2 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint8_t *rr = r + (ptrdiff_t)(j - 3) * (ptrdiff_t)as;
+                int t = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) t += (int)rr[k - 3] * fx[k];
+                t2 += clip_u8((t + 64) >> 7) * fy[j];
+            }
+            v = clip_u8((t2 + 64) >> 7);
+        }
+        const int dd = v - (int)b[(size_t)y * bs + x];
+        sum += dd;
+        sse += (uint32_t)(dd * dd);
+    }
+    sum = wave_sum_i32(sum);
+    sse = wave_sum_u32(sse);
+    sse_out = sse;
+    return sse - (uint32_t)(((i64)sum * sum) / n);
+}
+
 __device__ __forceinline__ bool sp_in_range(const SpCtx &s, SvtHipMv mv) {
     return mv.col >= s.jb.col_min && mv.col <= s.jb.col_max && mv.row >= s.jb.row_min && mv.row <= s.jb.row_max;
 }
@@ -241,6 +304,22 @@ __device__ __forceinline__ uint32_t sp_check(const SpCtx &s, SvtHipMv this_mv, S
     return cost;
 }
 
+// svt_check_better (mcomp.c:210-238): the accurate search's test of one candidate
+__device__ __forceinline__ uint32_t sp_check_accurate(const SpCtx &s, SvtHipMv this_mv, SvtHipMv &best_mv, uint32_t &besterr, uint32_t &sse1, int &distortion, int &is_better) {
+    uint32_t cost;
+    if (sp_in_range(s, this_mv)) {
+        uint32_t sse;
+        const uint8_t *ref = s.ref + (ptrdiff_t)(this_mv.row >> 3) * (ptrdiff_t)s.d->ref_stride + (this_mv.col >> 3);
+        const int thismse = (int)wave_upsampled_variance(ref, s.d->ref_stride, this_mv.col & 7, this_mv.row & 7, s.d->subpel_search_type, s.src, s.d->src_stride, s.jb.width, s.jb.height, sse);
+        cost = (uint32_t)mv_err_cost(this_mv.row, this_mv.col, s.mc) + (uint32_t)thismse;
+        int weight = 100;
+        if (s.d->bias_fp && best_mv.col % 8 == 0 && best_mv.row % 8 == 0) weight = s.d->bias_fp;
+        if ((((u64)cost * (u64)(i64)weight) / 100) < besterr) { besterr = cost; best_mv = this_mv; distortion = thismse; sse1 = sse; is_better |= 1; }
+    } else
+        cost = INT_MAX;
+    return cost;
+}
+
 __device__ __forceinline__ SvtHipMv mv_of(int row, int col) { SvtHipMv m; m.row = (int16_t)row; m.col = (int16_t)col; return m; }
 
 __global__ void __launch_bounds__(64) md_subpel_kernel(const SubpelParams p) {
@@ -261,13 +340,22 @@ __global__ void __launch_bounds__(64) md_subpel_kernel(const SubpelParams p) {
         distortion = (int)wave_sub_pixel_variance(ref0, d.ref_stride, 0, 0, s.src, d.src_stride, w, h, sse);
         besterr    = (uint32_t)distortion + (uint32_t)mv_err_cost(bestmv.row, bestmv.col, s.mc);
     }
+    if (d.center_err && threadIdx.x == 0) d.center_err[job] = besterr; // what the functions leave in ctx->fp_me_dist
+    const bool accurate = d.search_method == 1; // svt_av1_find_best_sub_pixel_tree (mcomp.c:688-777)
+    int round = (3 - d.forced_stop) < (3 - !d.allow_hp) ? (3 - d.forced_stop) : (3 - !d.allow_hp); // FULL_PEL = 3
+    if (accurate && d.mvp_th > 0) { // its PD_PASS_1 / SPEL_ME branch (:702-722)
+        const int     mvp_err = (int)s.jb.best_mvp_dist + 1, me_err = (int)besterr + 1;
+        const int32_t deviation = ((me_err - mvp_err) * 100) / me_err;
+        const int     dc = bestmv.col - s.jb.best_mvp.col, dr = bestmv.row - s.jb.best_mvp.row;
+        if (deviation >= d.mvp_th) round = 1;
+        else if ((dc < 0 ? -dc : dc) > d.hp_mv_th || (dr < 0 ? -dr : dr) > d.hp_mv_th) round = round < 2 ? round : 2;
+    }
     if (s.jb.early_neigh_check_exit) done = true;
-    if (!done) {
+    if (!done && !accurate) { // (the accurate search tests the prediction's variance first, and normalises by w h / 4)
         const u64 th_normalizer = (u64)(i64)(((w * h) >> 3) * (int)(uint8_t)d.abs_th_mult * (d.qp >> 1));
         if (besterr < th_normalizer) done = true;
     }
-    const int round = (3 - d.forced_stop) < (3 - !d.allow_hp) ? (3 - d.forced_stop) : (3 - !d.allow_hp); // FULL_PEL = 3
-    if (!round) done = true;
+    if (!round && !accurate) done = true;
     if (!done) { // variance of the full-pel prediction itself (against the constant 128: svt_aom_eb_av1_var_offs with stride 0)
         int      sum = 0;
         uint32_t sse = 0;
@@ -282,6 +370,33 @@ __global__ void __launch_bounds__(64) md_subpel_kernel(const SubpelParams p) {
         const uint32_t var = sse - (uint32_t)(((i64)sum * sum) / n);
         const int block_var = (int)((var + ((1u << s.jb.log2_pels) >> 1)) >> s.jb.log2_pels);
         if (block_var < d.pred_variance_th) done = true;
+    }
+    if (!done && accurate) {
+        const u64 th_normalizer = (u64)(i64)(((w * h) >> 2) * (int)(uint8_t)d.abs_th_mult * (d.qp >> 1));
+        if (besterr < th_normalizer || !round) done = true;
+        for (int iter = 0; iter < round && !done; ++iter) {
+            const SvtHipMv c = bestmv; // iter_center_mv
+            int dummy = 0;
+            // svt_first_level_check (:260-287)
+            const uint32_t left  = sp_check_accurate(s, mv_of(c.row, c.col - hstep), bestmv, besterr, sse1, distortion, dummy);
+            const uint32_t right = sp_check_accurate(s, mv_of(c.row, c.col + hstep), bestmv, besterr, sse1, distortion, dummy);
+            const uint32_t up    = sp_check_accurate(s, mv_of(c.row - hstep, c.col), bestmv, besterr, sse1, distortion, dummy);
+            const uint32_t down  = sp_check_accurate(s, mv_of(c.row + hstep, c.col), bestmv, besterr, sse1, distortion, dummy);
+            SvtHipMv diag_step = mv_of(up <= down ? -hstep : hstep, left <= right ? -hstep : hstep);
+            sp_check_accurate(s, mv_of(c.row + diag_step.row, c.col + diag_step.col), bestmv, besterr, sse1, distortion, dummy);
+            if (!(c.row == bestmv.row && c.col == bestmv.col) && d.iters_per_step > 1) { // svt_second_level_check_v2 (:292-350)
+                if (c.row == bestmv.row) diag_step.row = (int16_t)-diag_step.row;
+                else if (c.col == bestmv.col) diag_step.col = (int16_t)-diag_step.col;
+                const SvtHipMv row_bias = mv_of(bestmv.row + diag_step.row, bestmv.col), col_bias = mv_of(bestmv.row, bestmv.col + diag_step.col),
+                               diag_bias = mv_of(bestmv.row + diag_step.row, bestmv.col + diag_step.col);
+                int has_better = 0;
+                sp_check_accurate(s, row_bias, bestmv, besterr, sse1, distortion, has_better);
+                sp_check_accurate(s, col_bias, bestmv, besterr, sse1, distortion, has_better);
+                if (has_better) sp_check_accurate(s, diag_bias, bestmv, besterr, sse1, distortion, has_better);
+            }
+            hstep >>= 1;
+        }
+        done = true;
     }
     if (!done) {
         const int sdr = (uint8_t)d.skip_diag_refinement;
@@ -359,6 +474,8 @@ extern "C" int svt_hip_md_subpel_batch(SvtHipContext *ctx, const SvtHipSubpelBat
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "md sub-pel batch: a mandatory pointer is null");
     if (d->mv_cost_type < 0 || d->mv_cost_type > SVT_HIP_MV_COST_NONE || d->forced_stop < 0 || d->forced_stop > 3)
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "md sub-pel batch: mv_cost_type %d / forced_stop %d", d->mv_cost_type, d->forced_stop);
+    if (d->search_method < 0 || d->search_method > 1 || (d->search_method == 1 && (d->subpel_search_type < SVT_HIP_USE_2_TAPS || d->subpel_search_type > SVT_HIP_USE_8_TAPS)))
+        return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "md sub-pel batch: search_method %d / subpel_search_type %d", d->search_method, d->subpel_search_type);
     if (d->mv_cost_type == SVT_HIP_MV_COST_ENTROPY && (!d->mvjcost || !d->mvcost[0] || !d->mvcost[1]))
         return svt_hip_fail(ctx, SVT_HIP_ERR_BAD_PARAM, "md sub-pel batch: MV_COST_ENTROPY needs the joint and component cost tables");
     hipSetDevice(ctx->device);

@@ -135,7 +135,8 @@ def run_fullpel_hip(ctx, src, ref, rounds, cost_type, epb, tables):
     return trace
 
 
-# MdSubPelSearchCtrls-like settings: (allow_hp, forced_stop, iters_per_step, pred_variance_th, abs_th_mult, round_dev_th, skip_diag_refinement, bias_fp, mv_cost_type)
+# MdSubPelSearchCtrls-like settings: (allow_hp, forced_stop, iters_per_step, pred_variance_th, abs_th_mult, round_dev_th, skip_diag_refinement, bias_fp, mv_cost_type
+#                                       [, search_method, subpel_search_type, mvp_th, hp_mv_th])
 SUBPEL_SETTINGS = [
     (0, 0, 2, 0, 0, 2147483647, 0, 0, 0),        # everything on: quarter-pel (no hp), two levels per step, entropy MV cost
     (1, 0, 2, 0, 0, 2147483647, 1, 0, 0),        # eighth-pel, diagonal refinement only when the cardinal points improved
@@ -143,7 +144,17 @@ SUBPEL_SETTINGS = [
     (0, 2, 2, 0, 0, 2147483647, 3, 100, 4),      # half-pel only, MV_COST_OPT with its early exit, full-pel bias
     (1, 0, 2, 0, 0, 2147483647, 4, 110, 4),      # org_error 0: never the diagonal / second level
     (0, 3, 2, 0, 0, 2147483647, 0, 0, 0),        # forced_stop FULL_PEL: the centre error only
+    # svt_av1_find_best_sub_pixel_tree (search_method 1): the accurate search on svt_aom_upsampled_pred
+    (1, 0, 2, 0, 0, 2147483647, 0, 0, 0, 1, 3, 0, 0),    # eighth-pel, 8 taps, two levels per step
+    (0, 0, 2, 0, 0, 2147483647, 0, 0, 0, 1, 2, 0, 0),    # quarter-pel, 4 taps
+    (1, 0, 1, 30, 1, 2147483647, 0, 105, 4, 1, 1, 0, 0),  # 2 taps (bilinear table), one level, variance / absolute thresholds, full-pel bias, MV_COST_OPT
+    (1, 0, 2, 0, 0, 2147483647, 0, 0, 0, 1, 3, 20, 16),   # the PD_PASS_1 branch: round limited by the distance to the best MVP (mvp_th, hp_mv_th)
+    (0, 2, 2, 0, 0, 2147483647, 0, 0, 0, 1, 3, 0, 0),     # half-pel only
 ]
+
+
+def full_setting(setting):
+    return tuple(setting) + (0, 0, 0, 0)[len(setting) - 9:] if len(setting) < 13 else tuple(setting)
 
 
 def subpel_jobs(rng, n):
@@ -161,22 +172,26 @@ def subpel_jobs(rng, n):
         lim = int(rng.choice([9, 40, 2000]))  # tight limits cut the tree at the range test
         j["col_min"], j["col_max"], j["row_min"], j["row_max"] = smv[1] - lim, smv[1] + lim, smv[0] - lim, smv[0] + lim
         j["early_exit_th"] = 1020 - (max(bw, bh) >> 2)
+        j["best_mvp_dist"] = int(rng.integers(0, 40000))  # (read by the tree search's PD_PASS_1 branch only)
+        j["best_mvp"] = smv + rng.integers(-40, 41, 2)
     return jobs
 
 
 def subpel_desc(src, ref, jobs, setting, epb, qp, tables, out):
     jc, tr, tc = tables
-    hp, stop, iters, pvt, atm, rdt, sdr, bias, ctype = setting
+    hp, stop, iters, pvt, atm, rdt, sdr, bias, ctype, method, taps, mvp_th, hp_mv_th = full_setting(setting)
     d = abi.SubpelBatchDesc(n_jobs=len(jobs), src_stride=src.shape[1], ref_stride=ref.shape[1], src=src.ctypes.data, ref=ref.ctypes.data, jobs=jobs.ctypes.data, allow_hp=hp,
                             forced_stop=stop, iters_per_step=iters, pred_variance_th=pvt, abs_th_mult=atm, round_dev_th=rdt, skip_diag_refinement=sdr, bias_fp=bias, qp=qp,
+                            search_method=method, subpel_search_type=taps, mvp_th=mvp_th, hp_mv_th=hp_mv_th,
                             mv_cost_type=ctype, error_per_bit=epb, mvjcost=jc.ctypes.data, best_mv=out["best_mv"].ctypes.data, besterr=out["besterr"].ctypes.data,
-                            distortion=out["distortion"].ctypes.data, sse=out["sse"].ctypes.data)
+                            distortion=out["distortion"].ctypes.data, sse=out["sse"].ctypes.data, center_err=out["center_err"].ctypes.data)
     d.mvcost[0], d.mvcost[1] = tr.ctypes.data + 4 * MV_CENTRE, tc.ctypes.data + 4 * MV_CENTRE
     return d
 
 
 def subpel_out(n):
-    return {"best_mv": np.zeros((n, 2), np.int16), "besterr": np.zeros(n, np.uint32), "distortion": np.zeros(n, np.int32), "sse": np.zeros(n, np.uint32)}
+    return {"best_mv": np.zeros((n, 2), np.int16), "besterr": np.zeros(n, np.uint32), "distortion": np.zeros(n, np.int32), "sse": np.zeros(n, np.uint32),
+            "center_err": np.zeros(n, np.uint32)}
 
 
 def run_subpel_cpu(fn, src, ref, jobs, setting, epb, qp, tables):
@@ -191,21 +206,23 @@ def run_subpel_hip(ctx, src, ref, jobs, setting, epb, qp, tables):
     L = api.lib()
     ext = torch.cuda.ExternalStream(ctx.stream)
     jc, tr, tc = tables
-    hp, stop, iters, pvt, atm, rdt, sdr, bias, ctype = setting
+    hp, stop, iters, pvt, atm, rdt, sdr, bias, ctype, method, taps, mvp_th, hp_mv_th = full_setting(setting)
     n = len(jobs)
     with torch.cuda.stream(ext):
         t = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.uint8).reshape(-1)).cuda() for k, v in dict(src=src, ref=ref, jc=jc, tr=tr, tc=tc, jobs=jobs).items()}
         o = {"best_mv": torch.zeros(2 * n, dtype=torch.int16, device="cuda"), "besterr": torch.zeros(n, dtype=torch.int32, device="cuda"),
-             "distortion": torch.zeros(n, dtype=torch.int32, device="cuda"), "sse": torch.zeros(n, dtype=torch.int32, device="cuda")}
+             "distortion": torch.zeros(n, dtype=torch.int32, device="cuda"), "sse": torch.zeros(n, dtype=torch.int32, device="cuda"),
+             "center_err": torch.zeros(n, dtype=torch.int32, device="cuda")}
         d = abi.SubpelBatchDesc(n_jobs=n, src_stride=src.shape[1], ref_stride=ref.shape[1], src=t["src"].data_ptr(), ref=t["ref"].data_ptr(), jobs=t["jobs"].data_ptr(), allow_hp=hp,
                                 forced_stop=stop, iters_per_step=iters, pred_variance_th=pvt, abs_th_mult=atm, round_dev_th=rdt, skip_diag_refinement=sdr, bias_fp=bias, qp=qp,
+                                search_method=method, subpel_search_type=taps, mvp_th=mvp_th, hp_mv_th=hp_mv_th,
                                 mv_cost_type=ctype, error_per_bit=epb, mvjcost=t["jc"].data_ptr(), best_mv=o["best_mv"].data_ptr(), besterr=o["besterr"].data_ptr(),
-                                distortion=o["distortion"].data_ptr(), sse=o["sse"].data_ptr())
+                                distortion=o["distortion"].data_ptr(), sse=o["sse"].data_ptr(), center_err=o["center_err"].data_ptr())
         d.mvcost[0], d.mvcost[1] = t["tr"].data_ptr() + 4 * MV_CENTRE, t["tc"].data_ptr() + 4 * MV_CENTRE
         ctx.check(L.svt_hip_md_subpel_batch(ctx._h, C.byref(d)), "svt_hip_md_subpel_batch")
         ctx.sync()
     return {"best_mv": o["best_mv"].cpu().numpy().reshape(n, 2), "besterr": o["besterr"].cpu().numpy().view(np.uint32), "distortion": o["distortion"].cpu().numpy(),
-            "sse": o["sse"].cpu().numpy().view(np.uint32)}
+            "sse": o["sse"].cpu().numpy().view(np.uint32), "center_err": o["center_err"].cpu().numpy().view(np.uint32)}
 
 
 FULLPEL_GRID = [(dist, psad, ctype) for dist in (0, 1) for psad in (0, 1) for ctype in (0, 4)]

@@ -35,7 +35,7 @@ def test_fullpel_chain_oracle_equals_reference(oracle, ref, dist, psad, ctype):
 
 
 @pytest.mark.parametrize("si", range(len(mc.SUBPEL_SETTINGS)))
-def test_subpel_tree_pruned_oracle_equals_reference(oracle, ref, si):
+def test_subpel_tree_searches_oracle_equals_reference(oracle, ref, si):
     rng = np.random.default_rng(300 + si)
     src, refp = mc.planes(11 + si)
     tables = mc.cost_tables(rng)

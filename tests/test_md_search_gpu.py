@@ -29,7 +29,7 @@ def test_fullpel_chain(hip_ctx, oracle, gi):
 
 
 @pytest.mark.parametrize("si", range(len(mc.SUBPEL_SETTINGS)))
-def test_subpel_tree_pruned(hip_ctx, oracle, si):
+def test_subpel_tree_searches(hip_ctx, oracle, si):
     rng = np.random.default_rng(300 + si)
     src, refp = mc.planes(11 + si)
     tables = mc.cost_tables(rng)
