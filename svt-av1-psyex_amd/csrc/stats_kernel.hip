@@ -354,6 +354,7 @@ template <typename Pix> __device__ int32_t psy_tile_energy(const View<Pix> &pv, 
 struct StatsParams {
     SvtHipBlockStatsDesc d;
     uint32_t n_front; // workgroups [0, n_front) of the launch take the regions (d.pyramids), the rest the flat jobs
+    uint32_t jpw;     // flat jobs per wave: kJobsPerWave, or 1 when the batch is too small to fill the chip that way (a wave's jobs run one after the other)
 };
 
 constexpr int kJobsPerWave = 4; // a multiple of 4, at most 16 (the psy prefix sum runs inside one DPP row).  Measured: 16 jobs per wave bring the 2160p psy batch from 0.29 to 0.21 ms but the 1080p statistics batch from 0.065 to 0.22 ms (sixteen 64x64 blocks in a row make a long, lonely wave)
@@ -484,7 +485,7 @@ struct FlatLds { // one wave's tiles
 template <typename Pix> __device__ __forceinline__ void block_stats_flat(const StatsParams &p, FlatLds &F, const uint32_t wave, const int lane) {
     HadLds   &L = F.L;
     uint32_t *tile0 = F.tile0, *esum = F.esum;
-    const uint32_t j0 = wave * kJobsPerWave, j1 = j0 + kJobsPerWave < p.d.n_jobs ? j0 + kJobsPerWave : p.d.n_jobs;
+    const uint32_t j0 = wave * p.jpw, j1 = j0 + p.jpw < p.d.n_jobs ? j0 + p.jpw : p.d.n_jobs;
     const int      nj = (int)(j1 - j0);
     // Four consecutive plain 8x8 blocks share one matrix-core tile: their residuals side by side in the LDS tile, one pair of MFMAs, four SATDs
     uint32_t quad8 = 0; // bit g: jobs 4g .. 4g + 3 of the wave
@@ -759,7 +760,7 @@ template <typename Pix> __global__ void __launch_bounds__(256) block_stats4_kern
     if (blockIdx.x < p.n_front) block_stats_pyramid4<Pix>(p, U.S, blockIdx.x);
     else {
         const uint32_t wave = (blockIdx.x - p.n_front) * 4 + (threadIdx.x >> 6);
-        if (wave * kJobsPerWave < p.d.n_jobs) block_stats_flat<Pix>(p, U.F[threadIdx.x >> 6], wave, threadIdx.x & 63);
+        if (wave * p.jpw < p.d.n_jobs) block_stats_flat<Pix>(p, U.F[threadIdx.x >> 6], wave, threadIdx.x & 63);
     }
 }
 
@@ -895,7 +896,12 @@ int svt_hip_block_stats_batch(SvtHipContext *ctx, const SvtHipBlockStatsDesc *d)
     hipSetDevice(ctx->device);
     StatsParams p;
     p.d = *d;
-    const uint32_t flat = (d->n_jobs + kJobsPerWave - 1) / kJobsPerWave; // waves of the flat list
+    // a wave works through its jobs one after the other: four per wave (shared matrix-core tiles for 8x8 blocks, fewer waves) only when that
+    // still gives every CU several waves -- a one-picture batch's edge jobs are otherwise the launch's critical path
+    // (hadamard_path batches only: the psy / facade batches finish a wave's four jobs side by side, one tile per lane -- measured 32 us with four
+    // jobs per wave, 42 us with one, on the 2160p batch's 3,720 edge jobs)
+    p.jpw = (d->satd && d->n_jobs < (uint32_t)ctx->num_cus * 8u * kJobsPerWave) ? 1 : kJobsPerWave;
+    const uint32_t flat = (d->n_jobs + p.jpw - 1) / p.jpw; // waves of the flat list
     p.n_front = d->n_pyramids;
     if (d->satd && d->n_pyramids) // (8-bit planes: checked above)
         hipLaunchKernelGGL(block_stats4_kernel<uint8_t>, dim3(d->n_pyramids + (flat + 3) / 4), dim3(256), 0, ctx->stream, p);
