@@ -35,7 +35,10 @@ __device__ __forceinline__ u64 dense_group(const uint32_t (&wv)[6], const uint32
 
 } // namespace
 
-extern "C" __global__ void __launch_bounds__(64, 3)
+#ifndef SVT_HIP_ME_DENSE_WAVES
+#define SVT_HIP_ME_DENSE_WAVES 3
+#endif
+extern "C" __global__ void __launch_bounds__(64, SVT_HIP_ME_DENSE_WAVES)
 svt_hip_me_dense_kernel(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams, const MeDenseEntry *__restrict__ gent) {
     typedef const SVT_CONST_AS MeBatchHeader CHeader;
     typedef const SVT_CONST_AS MeDenseEntry  CEntry;
