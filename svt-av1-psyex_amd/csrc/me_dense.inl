@@ -214,7 +214,9 @@ namespace {
 
 // The launch's dense entries: every (picture, searched (list, reference) pair, kind) whose search window is known before any search
 // result.  Returns the number of entries; units = the total number of units (0: nothing to do).
-uint32_t dense_plan(const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures, MeDenseEntry *ent, uint32_t *units) {
+// `target_groups`: (octets x search rows x source rows) a lane aims for per unit; `seg_rows`: search rows of a unit's dy segment when an area is
+// taller than `seg_max` -- the knobs that trade unit length against unit count.
+uint32_t dense_plan_with(const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures, MeDenseEntry *ent, uint32_t *units, uint32_t target_groups, int seg_max, int seg_rows) {
     uint32_t n = 0;
     struct Cost { uint32_t cost; };
     Cost cost[SVT_HIP_ME_DENSE_MAX_ENTRIES];
@@ -243,10 +245,10 @@ uint32_t dense_plan(const MeKernelParams *params, const uint32_t *n_jobs, uint32
                     memset(&e, 0, sizeof(e));
                     e.pic = (uint16_t)pi; e.li = (uint8_t)li; e.ri = (uint8_t)ri; e.k = (uint8_t)((li ? r0n : 0) + ri); e.kind = (uint8_t)kind;
                     e.noct = (uint16_t)((sa_w + 7) >> 3);
-                    e.n_seg = (uint16_t)(sa_h <= 64 ? 1 : (sa_h + 47) / 48);
+                    e.n_seg = (uint16_t)(sa_h <= seg_max ? 1 : (sa_h + seg_rows - 1) / seg_rows);
                     e.seg_len = (uint16_t)((sa_h + e.n_seg - 1) / e.n_seg);
                     const uint32_t groups = (uint32_t)e.noct * e.seg_len * 8u; // of one block
-                    uint32_t nos = (groups + kDenseTargetGroups - 1) / kDenseTargetGroups;
+                    uint32_t nos = (groups + target_groups - 1) / target_groups;
                     nos = nos < 1 ? 1 : (nos > e.noct ? e.noct : nos);
                     while (e.noct % nos) nos++; // a divisor of the octet count: every lane of a block walks the same number of octets
                     e.nos = (uint16_t)nos;
@@ -271,6 +273,15 @@ uint32_t dense_plan(const MeKernelParams *params, const uint32_t *n_jobs, uint32
         total += (uint32_t)ent[i].n_rows * ent[i].n_seg * ent[i].n_chunk;
     }
     *units = total;
+    return n;
+}
+
+// A launch of many blocks gets long units (384 groups per lane: few waves' worth of set-up per |a-b|); a launch of few blocks -- a rank's band
+// at 8 GPUs, a single small picture -- would leave most of the chip's resident waves without a unit that way, so it is cut finer.
+uint32_t dense_plan(const MeKernelParams *params, const uint32_t *n_jobs, uint32_t n_pictures, MeDenseEntry *ent, uint32_t *units, uint32_t resident_waves) {
+    uint32_t n = dense_plan_with(params, n_jobs, n_pictures, ent, units, kDenseTargetGroups, 64, 48);
+    if (*units && *units < 3u * resident_waves) n = dense_plan_with(params, n_jobs, n_pictures, ent, units, kDenseTargetGroups / 2, 32, 24);
+    if (*units && *units < 3u * resident_waves) n = dense_plan_with(params, n_jobs, n_pictures, ent, units, kDenseTargetGroups / 4, 16, 16);
     return n;
 }
 

@@ -2298,7 +2298,7 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     // the dense pre-pass: entries, the slot buffer (one slot per job, searched reference and kind; 0xFF = "not filled")
     static thread_local MeDenseEntry entries[SVT_HIP_ME_DENSE_MAX_ENTRIES];
     uint32_t n_entries = 0, n_units = 0;
-    if (ctx->me_dense) n_entries = dense_plan(params, n_jobs, n_pictures, entries, &n_units);
+    if (ctx->me_dense) n_entries = dense_plan(params, n_jobs, n_pictures, entries, &n_units, (uint32_t)ctx->num_cus * 4u * SVT_HIP_ME_DENSE_WAVES);
     auto grow = [&](void **buf, size_t *have, size_t need) -> int { // a lane's device buffers grow on demand (earlier launches of the lane may still read the old one)
         if (need <= *have) return SVT_HIP_OK;
         if (*buf) {
