@@ -812,29 +812,46 @@ __device__ __forceinline__ void direct_rows(uint8_t *arena, const uint8_t *src, 
     for (int i = 0; i < 8; i++) out[i] = a[i];
 }
 
-// do the stage's requests st.req[0 .. nreq) qualify for run_small_searches_direct?  (wave-uniform answer)
-__device__ __forceinline__ bool small_direct_ok(const St &st) {
+// do the stage's requests st.req[0 .. nreq) qualify for run_small_searches_direct?  (wave-uniform answer)  Block shape, row step, source view
+// and stride are the stage's; the search AREAS may differ from request to request (an edge block's are clipped one by one) as long as each is
+// small and all their octet items fit one slice of the wave.  `q_total`: the items of a slice.
+__device__ __forceinline__ bool small_direct_ok(const St &st, int *q_total = nullptr) {
     const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
     const Req &r0 = st.req[0];
-    const int  w = (int16_t)uni((uint32_t)r0.sa_w), h = (int16_t)uni((uint32_t)r0.sa_h), bw = (int)uni(r0.bw), bh = (int)uni(r0.bh), rs = (int)uni(r0.rs),
-               level = (int)uni(r0.level), stride = (int)uni((uint32_t)r0.stride);
+    const int  bw = (int)uni(r0.bw), bh = (int)uni(r0.bh), rs = (int)uni(r0.rs), level = (int)uni(r0.level), stride = (int)uni((uint32_t)r0.stride);
     bool ok = true;
+    int  per = 0;
     if (lane < nreq) {
         const Req &r = st.req[lane];
-        ok = r.sa_w == w && r.sa_h == h && r.bw == bw && r.bh == bh && r.rs == rs && r.level == level && (int)r.stride == stride && !r.skip_even && !r.done;
+        const int  w = r.sa_w, h = r.sa_h;
+        ok  = w > 0 && h > 0 && w * h <= kNarrowMaxPos && r.bw == bw && r.bh == bh && r.rs == rs && r.level == level && (int)r.stride == stride && !r.skip_even && !r.done;
+        per = ((w + 7) >> 3) * h;
     }
-    if (!__all(ok) || w <= 0 || h <= 0 || w * h > kNarrowMaxPos || (bw != 32 && bw != 64) || nreq > kMaxReq) return false;
-    return ((w + 7) >> 3) * h * nreq <= kThreads; // octet items of one slice
+    if (!__all(ok) || (bw != 32 && bw != 64) || nreq > kMaxReq || nreq <= 0) return false;
+    const int q = (int)wave_sum_u32((uint32_t)per);
+    if (q_total) *q_total = q;
+    return q <= kThreads;
 }
 template <int DEPTH = 1> __device__ __forceinline__ bool run_small_searches_direct(Shared &sh PROF_PARAM) {
     St       &st   = sh.st;
     const int lane = threadIdx.x, nreq = (int)uni((uint32_t)st.nreq);
-    // every search like the first one, few positions, whole-vector source rows
-    if (!small_direct_ok(st)) return false;
+    // few positions per search, whole-vector source rows, one block shape
+    int Q = 0; // octet items of one slice
+    if (!small_direct_ok(st, &Q)) return false;
+    Q = (int)uni((uint32_t)Q);
     const Req &r0 = st.req[0];
-    const int  w = (int16_t)uni((uint32_t)r0.sa_w), h = (int16_t)uni((uint32_t)r0.sa_h), bw = (int)uni(r0.bw), bh = (int)uni(r0.bh), rs = (int)uni(r0.rs),
-               level = (int)uni(r0.level);
-    const int ng = (w + 7) >> 3, per = ng * h, Q = per * nreq; // octet items of one slice
+    const int  bw = (int)uni(r0.bw), bh = (int)uni(r0.bh), rs = (int)uni(r0.rs), level = (int)uni(r0.level);
+    // where a request's items start inside a slice: exclusive prefix of its item count over the requests (lane <-> request), parked in the
+    // requests' key slots until the keys themselves are written
+    {
+        int per = 0;
+        if (lane < nreq) per = ((st.req[lane].sa_w + 7) >> 3) * st.req[lane].sa_h;
+        int incl = per;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((lane & 31) >= o) incl += t; } // (kMaxReq = 32 requests)
+        if (lane < nreq) st.req_key[lane] = (u64)(uint32_t)(incl - per);
+    }
+    wave_sync();
     int       S        = imin(bh, (int)uni(div_by_rcp((uint32_t)kThreads, rcp_of((uint32_t)Q))));
     const int rows_per = (int)uni(div_by_rcp((uint32_t)(bh + S - 1), rcp_of((uint32_t)S)));
     S                  = (int)uni(div_by_rcp((uint32_t)(bh + rows_per - 1), rcp_of((uint32_t)rows_per)));
@@ -843,14 +860,15 @@ template <int DEPTH = 1> __device__ __forceinline__ bool run_small_searches_dire
     const int      sp  = (level == 2) ? kSrc64Pitch : (level == 1 ? kSrc32Pitch : kSrc16Pitch), srs = rs >> sh.cshift;
     const long long wstep = (long long)rs * (long long)(int)uni((uint32_t)r0.stride);
     const bool mine = lane < Q * S;
-    int req = 0, y = 0, g = 0, e0 = 0, rows = 0;
+    int req = 0, y = 0, g = 0, e0 = 0, rows = 0, w = 1;
     const uint8_t *wp = nullptr;
     if (mine) {
         const int slice = (int)div_by_rcp((uint32_t)lane, rcp_of((uint32_t)Q)), q = lane - slice * Q;
-        req = (int)div_by_rcp((uint32_t)q, rcp_of((uint32_t)per));
-        const int ql = q - req * per;
-        y = (int)div_by_rcp((uint32_t)ql, rcp_of((uint32_t)ng)); g = ql - y * ng;
+        for (int r = 1; r < nreq; r++) req += q >= (int)(uint32_t)st.req_key[r] ? 1 : 0; // (broadcast reads; the prefix is monotone)
         const Req &r = st.req[req];
+        w = r.sa_w;
+        const int ng = (w + 7) >> 3, ql = q - (int)(uint32_t)st.req_key[req];
+        y = (int)div_by_rcp((uint32_t)ql, rcp_of((uint32_t)ng)); g = ql - y * ng;
         e0   = slice * rows_per;
         rows = imin(e0 + rows_per, bh) - e0;
         wp   = r.win + (long long)y * r.stride + (long long)e0 * wstep + 8 * g;
@@ -869,11 +887,11 @@ template <int DEPTH = 1> __device__ __forceinline__ bool run_small_searches_dire
     }
     wave_sync();
     PROF(23);
-    const float w_rcp = rcp_of((uint32_t)w);
-    for (int req = 0; req < nreq; req++) { // lane <-> position in raster order: the first minimum is the smallest (sad << 6 | lane) (sad < 2^20)
-        const uint32_t k32 = wave_min_u32(lane < w * h ? (sad[req * kNarrowMaxPos + lane] << 6) | (uint32_t)lane : 0xFFFFFFFFu);
-        const int      wl = (int)(k32 & 63u), wy = (int)uni(div_by_rcp((uint32_t)wl, w_rcp)), wx = wl - wy * w;
-        if (lane == 0) st.req_key[req] = ((u64)(k32 >> 6) << 32) | ((uint32_t)wy << 16) | (uint32_t)wx;
+    for (int rq = 0; rq < nreq; rq++) { // lane <-> position in raster order: the first minimum is the smallest (sad << 6 | lane) (sad < 2^20)
+        const int      wr = (int16_t)uni((uint32_t)st.req[rq].sa_w), hr = (int16_t)uni((uint32_t)st.req[rq].sa_h);
+        const uint32_t k32 = wave_min_u32(lane < wr * hr ? (sad[rq * kNarrowMaxPos + lane] << 6) | (uint32_t)lane : 0xFFFFFFFFu);
+        const int      wl = (int)(k32 & 63u), wy = (int)uni(div_by_rcp((uint32_t)wl, rcp_of((uint32_t)wr))), wx = wl - wy * wr;
+        if (lane == 0) st.req_key[rq] = ((u64)(k32 >> 6) << 32) | ((uint32_t)wy << 16) | (uint32_t)wx;
     }
     wave_sync(); // the arena is free again
     return true;
