@@ -190,15 +190,15 @@ int   svt_hip_context_set_me_waves_per_cu(SvtHipContext *ctx, uint32_t waves);
 int   svt_hip_context_set_me_dense(SvtHipContext *ctx, int on);
 /* With the pre-pass on, the per-block pipeline can run STAGED: a chain of small kernels cut at its searches (control / level-1 searches / control /
  * level-2 searches / integer search and outputs), a block's state travelling through HBM between them -- each kernel has the register and
- * LDS budget of its own part only.  Blocks whose pre-HME / level-0 searches the pre-pass did not make go through the one-kernel form at the
- * end of the launch.  on = 0: never; 1 (default): launches of 2048 blocks and more (a small launch is latency-bound: one kernel serves it
+ * LDS budget of its own part only.  Blocks whose pre-HME / level-0 searches the pre-pass did not make, or whose level-1 / level-2 searches
+ * are too large for the search kernels' direct form, go through the one-kernel form at the end of the launch.  on = 0: never; 1 (default): launches of 2048 blocks and more (a small launch is latency-bound: one kernel serves it
  * better than nine); 2: every launch.  SVT_HIP_ME_STAGED=0/1/2 sets it at context creation.  Results are identical either way. */
 int   svt_hip_context_set_me_staged(SvtHipContext *ctx, int on);
 /* Measurement aid: with timing on, an ME launch records events around each kernel of its chain, and svt_hip_me_launch_times returns the
  * durations (ms) of the LAST launch enqueued on the context stream (it waits for that launch): ms[i] for kernel i of
  * svt_hip_me_chain_kernel_name(i) -- 0 for kernels the launch did not use (the one-kernel form uses the pre-pass and svt_hip_me_b64_kernel
  * only).  The events cost a few microseconds per kernel: off by default. */
-#define SVT_HIP_ME_CHAIN_KERNELS 9
+#define SVT_HIP_ME_CHAIN_KERNELS 7
 int   svt_hip_context_set_me_timing(SvtHipContext *ctx, int on);
 int   svt_hip_me_launch_times(SvtHipContext *ctx, float ms[SVT_HIP_ME_CHAIN_KERNELS]);
 const char *svt_hip_me_chain_kernel_name(int i);

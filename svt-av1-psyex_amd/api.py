@@ -125,10 +125,10 @@ class Context:
     def me_launch_times(self):
         """{kernel name: ms} of the last ME launch on the context stream (svt_hip_me_launch_times; waits for the launch); kernels it did not use are left out"""
         L = lib()
-        ms = (C.c_float * 9)()
+        ms = (C.c_float * 7)()
         self.check(L.svt_hip_me_launch_times(self._h, ms), "svt_hip_me_launch_times")
         L.svt_hip_me_chain_kernel_name.restype = C.c_char_p
-        return {L.svt_hip_me_chain_kernel_name(i).decode(): float(ms[i]) for i in range(9) if ms[i] > 0}
+        return {L.svt_hip_me_chain_kernel_name(i).decode(): float(ms[i]) for i in range(7) if ms[i] > 0}
 
     def set_me_counting(self, on):
         """ME waves report what they took from the dense pre-pass (svt_hip_context_set_me_counting); off by default"""

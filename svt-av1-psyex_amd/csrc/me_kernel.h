@@ -134,8 +134,6 @@ struct MeDenseEntry {
 // Staged launches (me_kernel.hip): per job a record in HBM -- the head of the block's state, its search requests, their results -- and a flag word
 #define SVT_HIP_ME_STAGE_BYTES 2560
 #define SVT_HIP_ME_JOB_DEFERRED 1u /* a search the pre-pass did not make: the whole-pipeline kernel makes the block (list 0) */
-#define SVT_HIP_ME_JOB_STAGED1 2u  /* its level-1 searches need the staged form (list 1) */
-#define SVT_HIP_ME_JOB_STAGED2 4u  /* its level-2 searches need the staged form (list 2) */
 /* u32 indices into a lane's queue_head block (2 KiB): [0, 8) the one-kernel form's band-queue counters, [16, 112) the profiling build's phase
  * sums, [112, 116) the dense counters, [200, 206) the three lists' cursors / counts */
 #define SVT_HIP_ME_LIST_CURSOR(l) (200 + 2 * (l))
@@ -167,7 +165,7 @@ struct MeBatchHeader {
     // whole-pipeline kernel, 1 / 2: level-1 / level-2 searches in the staged form)
     uint8_t   *stage;
     uint32_t  *job_flags;
-    uint32_t  *lists[3];
+    uint32_t  *lists[1]; // [0]: the deferred blocks
 };
 #ifdef __cplusplus
 static_assert(sizeof(MeBatchHeader) <= SVT_HIP_ME_HEADER_BYTES, "header size");

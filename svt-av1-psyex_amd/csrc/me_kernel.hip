@@ -160,22 +160,25 @@ struct LdsLayout { uint32_t src16, src32, src64, bsad, bmv, dense, win, total; }
 // cuts the same pipeline at its searches into small kernels -- each with the register / LDS budget of its own part, hence many more blocks in
 // flight per CU than the one-wave-does-everything form, whose time goes into the latencies of a long dependent chain:
 //   kMeMid1  zero-MV SADs, pre-HME / level-0 results from the pre-pass, level-1 requests     (control only)
-//   kMeS1    the level-1 searches of every block (direct form)      kMeS1f  the same for the blocks whose searches need the staged form
+//   kMeS1    the level-1 searches (direct form)
 //   kMeMid2  level-1 results -> level-2 requests                    (control only)
-//   kMeS2 / kMeS2f  the level-2 searches
+//   kMeS2    the level-2 searches (direct form)
 //   kMeTail  level-2 results, search centres, check-00, probe, integer search, pruning, candidates, outputs
-// A block's state (the head of St) and its search requests / results travel through HBM between them.
-constexpr int kMeFull = 0, kMeMid1 = 1, kMeS1 = 2, kMeS1f = 3, kMeMid2 = 4, kMeS2 = 5, kMeS2f = 6, kMeTail = 7;
+// A block's state (the head of St) and its search requests / results travel through HBM between them.  A block whose level-1 / level-2
+// searches do not qualify for the direct form (more than 32 positions, an empty area) -- or whose pre-HME / level-0 searches the pre-pass did
+// not make -- is DEFERRED: the one-kernel form makes it from scratch at the end of the launch (list mode).  (Round 3 first gave such blocks
+// search kernels of their own with the general staged form; once the direct form took requests with different areas -- edge blocks -- those
+// kernels were empty launches, 7 us each.)
+constexpr int kMeFull = 0, kMeMid1 = 1, kMeS1 = 2, kMeMid2 = 4, kMeS2 = 5, kMeTail = 7; // (3 and 6 were the staged-form search kernels)
 #ifndef SVT_HIP_ME_LIST_WAVES_PER_CU
 #define SVT_HIP_ME_LIST_WAVES_PER_CU 2
 #endif
 constexpr uint32_t kListWavesPerCu = SVT_HIP_ME_LIST_WAVES_PER_CU;
 constexpr uint32_t kStagedMinJobs = 2048; // blocks of a launch from which the staged form is used (measured at 4,080 blocks -- a rank's share at 8 GPUs: 0.58 ms staged, 0.59 ms one-kernel; at 8,160: 0.75 / 0.80)
-__host__ __device__ constexpr bool me_is_search(int m) { return m == kMeS1 || m == kMeS1f || m == kMeS2 || m == kMeS2f; }
-__host__ __device__ constexpr bool me_is_staged_search(int m) { return m == kMeS1f || m == kMeS2f; }
+__host__ __device__ constexpr bool me_is_search(int m) { return m == kMeS1 || m == kMeS2; }
 constexpr int kDirectWinBytes = 5120; // the direct searches' arena: a step's 64 x 5 window pieces, then the per-position sums [kMaxReq][kNarrowMaxPos] u32
 __host__ __device__ constexpr LdsLayout lds_layout(int n_slot, int cshift, int dense = 1, int mode = 0) {
-    const bool v16 = mode == kMeFull, v32 = mode == kMeFull || mode == kMeS1 || mode == kMeS1f, v64 = mode == kMeFull || mode == kMeS2 || mode == kMeS2f || mode == kMeTail;
+    const bool v16 = mode == kMeFull, v32 = mode == kMeFull || mode == kMeS1, v64 = mode == kMeFull || mode == kMeS2 || mode == kMeTail;
     const bool best = mode == kMeFull || mode == kMeTail, slots = dense && (mode == kMeFull || mode == kMeMid1);
     const uint32_t arena = (mode == kMeMid1 || mode == kMeMid2) ? 0u : (mode == kMeS1 || mode == kMeS2) ? (uint32_t)kDirectWinBytes : (uint32_t)kWinBytes;
     LdsLayout l = {};
@@ -1257,7 +1260,7 @@ __device__ __forceinline__ void push_zz_req(St &st, CPlane &rp, int dx, int dy, 
 #endif
 #define CTRL_PRIO(x) __builtin_amdgcn_s_setprio(x)
 
-// `launch_flags` bit 0: jobs come from a list (kMeFull: the deferred blocks of a staged launch; kMeS1f / kMeS2f always do).
+// `launch_flags` bit 0: jobs come from the list of deferred blocks (kMeFull at the end of a staged launch).
 constexpr size_t kPersistBytes = (offsetof(St, req) + 15) & ~(size_t)15; // the head of St that travels between the kernels of a staged launch
 template <int MODE>
 __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ ghdr, const MeKernelParams *__restrict__ gparams, const uint32_t launch_flags) {
@@ -1286,8 +1289,8 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
     // ~100 us of work).  The short kernels of a staged launch cannot afford one per job -- measured: ~0.1 us per wave and kernel, every one of
     // them serialised at the memory side -- so their waves take a contiguous share of the job range instead (neighbouring blocks, whose windows
     // overlap, still follow each other on one CU); only the few waves of the list kernels pull their (rare) jobs with an atomic.
-    constexpr int kList = MODE == kMeS1f ? 1 : MODE == kMeS2f ? 2 : 0; // which list a list-mode launch of this kernel walks
-    const bool list_mode = (launch_flags & 1u) || me_is_staged_search(MODE);
+    constexpr int kList = 0;
+    const bool list_mode = (launch_flags & 1u) != 0;
     const uint32_t n_total = hdr.job_base[hdr.n_pictures];
     // Wave i of a staged kernel walks band (i % 8) of the launch -- the band its XCD would pull from in the one-kernel form, workgroups being dealt
     // round-robin over the XCDs -- with the band's other waves, interleaved: what the chip works on at one time is a run of neighbouring blocks,
@@ -1383,12 +1386,10 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
         if constexpr (MODE != kMeFull && MODE != kMeMid1) {
             const uint32_t f = __hip_atomic_load(jflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (f & SVT_HIP_ME_JOB_DEFERRED) continue; // uniform: the whole-pipeline kernel makes this block at the end of the launch
-            if constexpr (MODE == kMeS1) { if (f & SVT_HIP_ME_JOB_STAGED1) continue; } // its level-1 searches take the staged form (kMeS1f)
-            if constexpr (MODE == kMeS2) { if (f & SVT_HIP_ME_JOB_STAGED2) continue; }
         }
         if constexpr (me_is_search(MODE)) {
             // ---- search-only kernels: the block's requests in, their keys out ------------------------------------------------
-            constexpr int lvl = (MODE == kMeS1 || MODE == kMeS1f) ? 1 : 2;
+            constexpr int lvl = MODE == kMeS1 ? 1 : 2;
             const int ox = (int)(bxi * 64), oy = (int)(byi * 64), rstep = 1 << cshift;
             PROF(24);
             import_reqs(gjob);
@@ -1409,8 +1410,7 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
             wave_sync();
             PROF(25);
             if (st.nreq) { // uniform
-                if constexpr (me_is_staged_search(MODE)) run_searches(sh PROF_ARG);
-                else (void)run_small_searches_direct<SVT_HIP_ME_SEARCH_DEPTH>(sh PROF_ARG); // (the Mid kernel routed the block here because it qualifies)
+                (void)run_small_searches_direct<SVT_HIP_ME_SEARCH_DEPTH>(sh PROF_ARG); // (the Mid kernel routed the block here because it qualifies)
             }
             wave_sync();
             u64 *keys = keys_of(gjob);
@@ -1940,20 +1940,16 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
                 else if (tid == 0) st.nreq = 0;
                 wave_sync();
             }
+            if (!defer && st.nreq && !small_direct_ok(st)) defer = true; // (uniform) the coming level's searches need the general form
             if (defer) {
                 if (tid == 0) {
                     *jflag = SVT_HIP_ME_JOB_DEFERRED;
                     hdr.lists[0][atomicAdd(&hdr.queue_head[SVT_HIP_ME_LIST_COUNT(0)], 1u)] = (uint32_t)gjob;
                 }
             } else {
-                constexpr int kL = MODE == kMeMid1 ? 1 : 2; // the list of blocks whose searches of the coming level need the staged form
-                const bool staged = st.nreq && !small_direct_ok(st); // (uniform)
                 export_state(gjob);
                 export_reqs(gjob);
-                if (tid == 0) {
-                    *jflag = flags | (staged ? (kL == 1 ? SVT_HIP_ME_JOB_STAGED1 : SVT_HIP_ME_JOB_STAGED2) : 0u);
-                    if (staged) hdr.lists[kL][atomicAdd(&hdr.queue_head[SVT_HIP_ME_LIST_COUNT(kL)], 1u)] = (uint32_t)gjob;
-                }
+                if (tid == 0) *jflag = flags;
             }
             wave_sync();
             continue;
@@ -2276,10 +2272,8 @@ __device__ __forceinline__ void me_b64_body(const MeBatchHeader *__restrict__ gh
 SVT_ME_KERNEL(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD)
 SVT_ME_KERNEL(svt_hip_me_mid1_kernel, kMeMid1, SVT_HIP_ME_MID_WAVES_PER_SIMD)
 SVT_ME_KERNEL(svt_hip_me_s1_kernel, kMeS1, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD)
-SVT_ME_KERNEL(svt_hip_me_s1f_kernel, kMeS1f, SVT_HIP_ME_WAVES_PER_SIMD)
 SVT_ME_KERNEL(svt_hip_me_mid2_kernel, kMeMid2, SVT_HIP_ME_MID_WAVES_PER_SIMD)
 SVT_ME_KERNEL(svt_hip_me_s2_kernel, kMeS2, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD)
-SVT_ME_KERNEL(svt_hip_me_s2f_kernel, kMeS2f, SVT_HIP_ME_WAVES_PER_SIMD)
 SVT_ME_KERNEL(svt_hip_me_tail_kernel, kMeTail, SVT_HIP_ME_TAIL_WAVES_PER_SIMD)
 #undef SVT_ME_KERNEL
 
@@ -2341,17 +2335,16 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     const bool staged = n_units && (ctx->me_staged == 2 || (ctx->me_staged == 1 && total >= kStagedMinJobs));
     if (staged) {
         const size_t stage_bytes = (size_t)total * SVT_HIP_ME_STAGE_BYTES, words = (size_t)total * sizeof(uint32_t);
-        if (int rc = grow(&lane->stage, &lane->stage_bytes, stage_bytes + 4 * words)) return rc;
+        if (int rc = grow(&lane->stage, &lane->stage_bytes, stage_bytes + 2 * words)) return rc;
         uint8_t *base = static_cast<uint8_t *>(lane->stage);
         hdr.stage     = base;
         hdr.job_flags = reinterpret_cast<uint32_t *>(base + stage_bytes);
-        for (int l = 0; l < 3; l++) hdr.lists[l] = reinterpret_cast<uint32_t *>(base + stage_bytes + (size_t)(1 + l) * words);
+        hdr.lists[0] = reinterpret_cast<uint32_t *>(base + stage_bytes + words); // the deferred blocks
         SVT_HIP_CHECK(ctx, hipMemsetAsync(lane->queue_head + 128, 0, SVT_HIP_ME_QUEUE_BLOCK_BYTES - 128 * sizeof(uint32_t), lane->stream)); // the staged kernels' counters and the lists
     }
     if (!ctx->me_attr_set) { // per context = per device; racing first calls set the same value
         const void *kernels[] = {reinterpret_cast<const void *>(svt_hip_me_b64_kernel),  reinterpret_cast<const void *>(svt_hip_me_mid1_kernel), reinterpret_cast<const void *>(svt_hip_me_s1_kernel),
-                                 reinterpret_cast<const void *>(svt_hip_me_s1f_kernel),  reinterpret_cast<const void *>(svt_hip_me_mid2_kernel), reinterpret_cast<const void *>(svt_hip_me_s2_kernel),
-                                 reinterpret_cast<const void *>(svt_hip_me_s2f_kernel),  reinterpret_cast<const void *>(svt_hip_me_tail_kernel)};
+                                 reinterpret_cast<const void *>(svt_hip_me_mid2_kernel), reinterpret_cast<const void *>(svt_hip_me_s2_kernel),   reinterpret_cast<const void *>(svt_hip_me_tail_kernel)};
         for (const void *k : kernels) SVT_HIP_CHECK(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)svt_hip_me_kernel_lds_bytes()));
         ctx->me_attr_set = true;
     }
@@ -2399,22 +2392,20 @@ int svt_hip_me_launch(SvtHipContext *ctx, SvtHipLane *lane, const MeKernelParams
     if (staged) {
         mark(1); launch(svt_hip_me_mid1_kernel, kMeMid1, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
         mark(2); launch(svt_hip_me_s1_kernel, kMeS1, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
-        mark(3); launch(svt_hip_me_s1f_kernel, kMeS1f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
-        mark(4); launch(svt_hip_me_mid2_kernel, kMeMid2, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
-        mark(5); launch(svt_hip_me_s2_kernel, kMeS2, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
-        mark(6); launch(svt_hip_me_s2f_kernel, kMeS2f, SVT_HIP_ME_WAVES_PER_SIMD, 1u);
-        mark(7); launch(svt_hip_me_tail_kernel, kMeTail, SVT_HIP_ME_TAIL_WAVES_PER_SIMD, 0u);
-        mark(8); launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 1u); // the deferred blocks (usually none: the waves find an empty list and leave)
+        mark(3); launch(svt_hip_me_mid2_kernel, kMeMid2, SVT_HIP_ME_MID_WAVES_PER_SIMD, 0u);
+        mark(4); launch(svt_hip_me_s2_kernel, kMeS2, SVT_HIP_ME_SEARCH_WAVES_PER_SIMD, 0u);
+        mark(5); launch(svt_hip_me_tail_kernel, kMeTail, SVT_HIP_ME_TAIL_WAVES_PER_SIMD, 0u);
+        mark(6); launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 1u); // the deferred blocks (usually none: the waves find an empty list and leave)
     } else {
-        mark(8); launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 0u);
+        mark(6); launch(svt_hip_me_b64_kernel, kMeFull, SVT_HIP_ME_WAVES_PER_SIMD, 0u);
     }
     mark(-1);
     SVT_HIP_CHECK(ctx, hipGetLastError());
     return SVT_HIP_OK;
 }
 
-static const char *const kChainKernelNames[SVT_HIP_ME_CHAIN_KERNELS] = {"svt_hip_me_dense_kernel", "svt_hip_me_mid1_kernel", "svt_hip_me_s1_kernel",  "svt_hip_me_s1f_kernel", "svt_hip_me_mid2_kernel",
-                                                                        "svt_hip_me_s2_kernel",    "svt_hip_me_s2f_kernel",  "svt_hip_me_tail_kernel", "svt_hip_me_b64_kernel"};
+static const char *const kChainKernelNames[SVT_HIP_ME_CHAIN_KERNELS] = {"svt_hip_me_dense_kernel", "svt_hip_me_mid1_kernel", "svt_hip_me_s1_kernel",  "svt_hip_me_mid2_kernel",
+                                                                        "svt_hip_me_s2_kernel",    "svt_hip_me_tail_kernel", "svt_hip_me_b64_kernel"};
 extern "C" const char *svt_hip_me_chain_kernel_name(int i) { return i >= 0 && i < SVT_HIP_ME_CHAIN_KERNELS ? kChainKernelNames[i] : nullptr; }
 
 extern "C" int svt_hip_context_set_me_counting(SvtHipContext *ctx, int on) {
