@@ -151,9 +151,10 @@ def test_fuzzed_search_controls_match_oracle(hip_ctx, seed):
     assert not compare(case.run_cpu("oracle"), case.run_hip(hip_ctx))
 
 
-def test_several_pictures_in_one_launch(hip_ctx):
+def test_several_pictures_in_one_launch(hip_ctx, me_form):
     """svt_hip_me_pictures_async: three different pictures (sizes, presets, reference counts, a row band) share one launch;
-    each must equal its own single-picture call."""
+    each must equal its own single-picture call.  Also svt_hip_context_set_me_timing / svt_hip_me_launch_times: the kernels the launch
+    used, each with a positive duration."""
     import ctypes as C
     import torch
     from svt_av1_psyex_amd import abi
@@ -174,8 +175,16 @@ def test_several_pictures_in_one_launch(hip_ctx):
         jobs.append((c.cfg, c.desc, cur, refs, res))
         keep.append((bufs, nb, n))
     torch.cuda.synchronize()
-    hip_ctx.me_pictures_async(jobs)
+    hip_ctx.set_me_timing(True)
+    try:
+        hip_ctx.me_pictures_async(jobs)
+        times = hip_ctx.me_launch_times()
+    finally:
+        hip_ctx.set_me_timing(False)
     hip_ctx.sync()
+    chain = {"svt_hip_me_dense_kernel", "svt_hip_me_b64_kernel"} | ({f"svt_hip_me_{k}_kernel" for k in ("mid1", "s1", "mid2", "s2", "tail")} if me_form == 2 else set())
+    assert set(times) == chain, times
+    assert all(0 < t < 50 for t in times.values()), times
     for c, (bufs, nb, n), exp in zip(cases, keep, expect):
         got = fill_unsearched(c.desc, {name: bufs[name].cpu().numpy().view(dt).reshape(nb, -1) for name, dt, _ in abi.RESULT_FIELDS})
         w64 = (c.desc.aligned_width + 63) // 64
@@ -288,3 +297,4 @@ def test_dense_prepass_skip_search_line_and_partial_octets(hip_ctx):
         hip_ctx.set_me_counting(False)
     assert not compare(want, got)
     assert taken > 0
+
