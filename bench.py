@@ -848,6 +848,11 @@ def main():
                                  "separate pass; profiles/r03_kernel_stats_bench.csv has rocprofv3's averages of the same kernels).  By the task's rule the bound is HBM; the search "
                                  "is issue-bound (SURVEY 8d): see valu_sad below", "longest_kernel": dom},
             "rd_roofline": rd_roof,
+            # the longest SINGLE kernel of the step, whatever launch it belongs to (the ME launch is a chain of kernels)
+            "dominant_single_kernel": max([{"name": k, "avg_launch_ms": v["avg_launch_ms"], "bound": "hbm", "achieved": v["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": v["frac"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"]} for k, v in rd_roof.items()]
+                                          + [{"name": k, "avg_launch_ms": round(v, 4), "bound": "valu (v_qsad_pk_u16_u8 issue)", "note": "one kernel of the ME chain: see roofline / roofline.valu_sad for the launch"}
+                                             for k, v in chain_ms.items()], key=lambda e: e["avg_launch_ms"]) if (rd_roof or chain_ms) else None,
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
         }
         if xch:

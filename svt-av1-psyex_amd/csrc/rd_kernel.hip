@@ -404,6 +404,9 @@ __host__ __device__ constexpr int rd_blocks_per_wave(int ts) { return 64 / rd_la
 #ifndef SVT_RD_WAVES_32
 #define SVT_RD_WAVES_32 4
 #endif
+#ifndef SVT_RD_SCAN_AHEAD
+#define SVT_RD_SCAN_AHEAD 16 /* coefficients per lane whose scan positions are fetched ahead of the quantizer loop */
+#endif
 #ifndef SVT_RD_WAVES_16
 #define SVT_RD_WAVES_16 4
 #endif
@@ -523,7 +526,15 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     const bool fast_q = q24 && !qm && p.d.quant_kind == 0 && !co_out && !dq_out && __all(pf == 0); // (co_out / dq_out: null for every job or none)
     if (fast_q) {
         static_assert(NP % LW == 0, "every lane of a block walks the same number of coefficients");
-        auto one = [&](int rc, int32_t zb, int32_t rnd, int32_t quant, int32_t qshift, int32_t deq) {
+        // The scan positions of a lane's first kScanAhead coefficients (the low frequencies: where the non-zero levels are) are fetched ahead,
+        // unconditionally, two to a register.  A load behind the `qv != 0` branch waits with s_waitcnt vmcnt(0) -- which on this ISA also
+        // waits for the coefficient STORES of the iterations before it: the loop stalled on store completion exactly where it has work.
+        constexpr int kScanAhead = NP / LW < SVT_RD_SCAN_AHEAD ? ((NP / LW) & ~1) : SVT_RD_SCAN_AHEAD;
+        static_assert(kScanAhead >= 2 && kScanAhead % 2 == 0 && NP / LW >= kScanAhead, "ahead of the loop");
+        uint32_t scan2[kScanAhead / 2];
+#pragma unroll
+        for (int k = 0; k < kScanAhead; k += 2) scan2[k / 2] = (uint32_t)(uint16_t)iscan[l + LW * k] | ((uint32_t)(uint16_t)iscan[l + LW * (k + 1)] << 16);
+        auto one = [&](int rc, int32_t zb, int32_t rnd, int32_t quant, int32_t qshift, int32_t deq, int ahead = -1) {
             const int r = rc / WP, c = rc - r * WP; // WP is a power of two
             const int32_t co = A[r * PA + c], sign = co >> 31, a = (co ^ sign) - sign;
             satd += (uint32_t)a;
@@ -534,7 +545,9 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
             qv = a >= zb ? qv : 0;
             const int32_t dq = __mul24(qv, deq) >> log_scale;
             const int32_t qs = (qv ^ sign) - sign, dqs = (dq ^ sign) - sign;
-            const uint32_t e = qv ? (uint32_t)iscan[rc] + 1u : 0u;
+            uint32_t e;
+            if (ahead >= 0) e = qv ? ((scan2[ahead >> 1] >> (16 * (ahead & 1))) & 0xFFFFu) + 1u : 0u; // (compile-time `ahead`)
+            else e = qv ? (uint32_t)iscan[rc] + 1u : 0u;
             eob = e > eob ? e : eob;
             qsum += (uint32_t)(qv > 63 ? 63 : qv);
             const int32_t dd = a - dq; // == |coeff - dqcoeff|: both carry the coefficient's sign
@@ -545,19 +558,21 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
             return qs;
         };
         const int ac0 = l != 0;
-        dc_q = one(l, zb_c[ac0], rnd_c[ac0], q.quant[ac0], q.quant_shift[ac0], q.dequant[ac0]);
+        dc_q = one(l, zb_c[ac0], rnd_c[ac0], q.quant[ac0], q.quant_shift[ac0], q.dequant[ac0], 0);
         const int32_t zb1 = zb_c[1], rnd1 = rnd_c[1], quant1 = q.quant[1], qshift1 = q.quant_shift[1], deq1 = q.dequant[1];
+#pragma unroll
+        for (int k = 1; k < kScanAhead; k++) one(l + LW * k, zb1, rnd1, quant1, qshift1, deq1, k);
         if constexpr (LW >= 32) {
-            // two coefficients per trip: two independent chains for the scheduler (the trip count NP / LW - 1 is odd: one coefficient first).
+            // two coefficients per trip: two independent chains for the scheduler.
             // Measured 64x64 0.718 -> 0.707 ms, 32x32 0.623 -> 0.611; at 16x16 the two extra registers cross an occupancy step (0.540 -> 0.564).
-            one(l + LW, zb1, rnd1, quant1, qshift1, deq1);
-            for (int rc = l + 2 * LW; rc < NP; rc += 2 * LW) {
+            static_assert((NP / LW - kScanAhead) % 2 == 0, "pairs");
+            for (int rc = l + kScanAhead * LW; rc < NP; rc += 2 * LW) {
                 one(rc, zb1, rnd1, quant1, qshift1, deq1);
                 one(rc + LW, zb1, rnd1, quant1, qshift1, deq1);
             }
         } else {
 #pragma unroll 4
-            for (int rc = l + LW; rc < NP; rc += LW) one(rc, zb1, rnd1, quant1, qshift1, deq1);
+            for (int rc = l + kScanAhead * LW; rc < NP; rc += LW) one(rc, zb1, rnd1, quant1, qshift1, deq1);
         }
     } else
     for (int rc = l; rc < NP; rc += LW) {
