@@ -697,21 +697,36 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     __syncthreads();
     {
         Pix *rec = (p.d.recon && valid) ? static_cast<Pix *>(p.d.recon) + jb.pred_offset : nullptr;
-        for (int i = l; i < RPR * H; i += LW) {
-            const int r = i / RPR, c = (i - r * RPR) * RUN;
-            const RunU pv = *reinterpret_cast<const RunU *>(pred + (size_t)r * p.d.pred_stride + c);
-            const RunU sv = *reinterpret_cast<const RunU *>(src + (size_t)r * p.d.src_stride + c);
-            RunU out;
+        // every run's prediction and source samples are requested BEFORE the first reconstruction run is stored: vector memory operations
+        // complete in issue order on this ISA, so a load issued behind a store waits for the store's acknowledgement as well
+        constexpr int NIT = (RPR * H + LW - 1) / LW; // runs per lane
+        RunU pv[NIT], sv[NIT];
 #pragma unroll
-            for (int k = 0; k < RUN; k++) {
-                int v = (int)pv[k] + A[r * PA + c + k];
-                v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
-                out[k] = (Pix)v;
-                const int e = (int)sv[k] - v;
-                const uint32_t ue = (uint32_t)(e < 0 ? -e : e);
-                sse += (u64)(ue * ue); // |e| < 2^16: the square fits 32 bits
+        for (int it = 0; it < NIT; it++) {
+            const int i = l + it * LW;
+            if (i < RPR * H) {
+                const int r = i / RPR, c = (i - r * RPR) * RUN;
+                pv[it] = *reinterpret_cast<const RunU *>(pred + (size_t)r * p.d.pred_stride + c);
+                sv[it] = *reinterpret_cast<const RunU *>(src + (size_t)r * p.d.src_stride + c);
             }
-            if (rec) *reinterpret_cast<RunU *>(rec + (size_t)r * p.d.pred_stride + c) = out;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = l + it * LW;
+            if (i < RPR * H) {
+                const int r = i / RPR, c = (i - r * RPR) * RUN;
+                RunU out;
+#pragma unroll
+                for (int k = 0; k < RUN; k++) {
+                    int v = (int)pv[it][k] + A[r * PA + c + k];
+                    v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
+                    out[k] = (Pix)v;
+                    const int e = (int)sv[it][k] - v;
+                    const uint32_t ue = (uint32_t)(e < 0 ? -e : e);
+                    sse += (u64)(ue * ue); // |e| < 2^16: the square fits 32 bits
+                }
+                if (rec) *reinterpret_cast<RunU *>(rec + (size_t)r * p.d.pred_stride + c) = out;
+            }
         }
     }
     sse = seg_sum_u64<LW>(sse);
