@@ -438,15 +438,34 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     constexpr int RUN = W < 8 ? W : 8, RPR = W / RUN; // run length, runs per row
     typedef Pix __attribute__((ext_vector_type(RUN), aligned(sizeof(Pix)))) RunU;
     uint32_t rmax = 0; // largest |residual| this lane produced
-    for (int i = l; i < RPR * H; i += LW) {
-        const int r = i / RPR, c = (i - r * RPR) * RUN;
-        const RunU sv = *reinterpret_cast<const RunU *>(src + (size_t)r * p.d.src_stride + c);
-        const RunU pv = *reinterpret_cast<const RunU *>(pred + (size_t)r * p.d.pred_stride + c);
+    {
+        // a lane's runs are fetched kResidualAhead at a time, all of a group in flight before the first is used (the loop's trip count depends
+        // on the lane: left to itself every run is a round trip of its own)
+        constexpr int NIT = (RPR * H + LW - 1) / LW, kResidualAhead = NIT < 4 ? NIT : 4;
+        for (int it0 = 0; it0 < NIT; it0 += kResidualAhead) {
+            RunU sv[kResidualAhead], pv[kResidualAhead];
 #pragma unroll
-        for (int k = 0; k < RUN; k++) {
-            const int32_t d = (int16_t)((int16_t)sv[k] - (int16_t)pv[k]);
-            A[r * PA + c + k] = d;
-            rmax = max(rmax, (uint32_t)(d < 0 ? -d : d));
+            for (int j = 0; j < kResidualAhead; j++) {
+                const int i = l + (it0 + j) * LW;
+                if (it0 + j < NIT && i < RPR * H) {
+                    const int r = i / RPR, c = (i - r * RPR) * RUN;
+                    sv[j] = *reinterpret_cast<const RunU *>(src + (size_t)r * p.d.src_stride + c);
+                    pv[j] = *reinterpret_cast<const RunU *>(pred + (size_t)r * p.d.pred_stride + c);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kResidualAhead; j++) {
+                const int i = l + (it0 + j) * LW;
+                if (it0 + j < NIT && i < RPR * H) {
+                    const int r = i / RPR, c = (i - r * RPR) * RUN;
+#pragma unroll
+                    for (int k = 0; k < RUN; k++) {
+                        const int32_t d = (int16_t)((int16_t)sv[j][k] - (int16_t)pv[j][k]);
+                        A[r * PA + c + k] = d;
+                        rmax = max(rmax, (uint32_t)(d < 0 ? -d : d));
+                    }
+                }
+            }
         }
     }
     // one answer for the wave (all its blocks): every residual small enough for the 24-bit multiplies of the forward passes?
