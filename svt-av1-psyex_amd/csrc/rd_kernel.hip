@@ -404,6 +404,9 @@ __host__ __device__ constexpr int rd_blocks_per_wave(int ts) { return 64 / rd_la
 #ifndef SVT_RD_WAVES_32
 #define SVT_RD_WAVES_32 4
 #endif
+#ifndef SVT_RD_RESIDUAL_AHEAD
+#define SVT_RD_RESIDUAL_AHEAD 8 /* runs of 8 samples a lane has in flight while it forms the residual */
+#endif
 #ifndef SVT_RD_SCAN_AHEAD
 #define SVT_RD_SCAN_AHEAD 16 /* coefficients per lane whose scan positions are fetched ahead of the quantizer loop */
 #endif
@@ -441,7 +444,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     {
         // a lane's runs are fetched kResidualAhead at a time, all of a group in flight before the first is used (the loop's trip count depends
         // on the lane: left to itself every run is a round trip of its own)
-        constexpr int NIT = (RPR * H + LW - 1) / LW, kResidualAhead = NIT < 4 ? NIT : 4;
+        constexpr int NIT = (RPR * H + LW - 1) / LW, kResidualAhead = NIT < SVT_RD_RESIDUAL_AHEAD ? NIT : SVT_RD_RESIDUAL_AHEAD;
         for (int it0 = 0; it0 < NIT; it0 += kResidualAhead) {
             RunU sv[kResidualAhead], pv[kResidualAhead];
 #pragma unroll
