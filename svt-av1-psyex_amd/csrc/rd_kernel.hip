@@ -328,11 +328,24 @@ template <int N, int CLAMP, int IM> __device__ __forceinline__ void inv_1d(int32
 // every node of an inverse pass is a sum of at most N pass inputs with weights of magnitude <= 1 (the stage clamps only shrink it): below 2^18
 // when N x the largest |input| is
 __device__ __forceinline__ bool ipass_fits_18_bits(uint32_t wave_max_abs_input, int n) { return (unsigned long long)wave_max_abs_input * (unsigned)n < (1u << 18); }
+// largest magnitude of a vector: the largest and the smallest element are tracked instead (one v_max3_i32 / v_min3_i32 per PAIR of elements
+// each; |x| first would be two instructions per element before the max)
+struct HiLo {
+    int32_t hi = 0, lo = 0;
+    __device__ __forceinline__ void take(int32_t a, int32_t b) { hi = max(max(hi, a), b); lo = min(min(lo, a), b); }
+    __device__ __forceinline__ void take(int32_t a) { hi = max(hi, a); lo = min(lo, a); }
+    __device__ __forceinline__ uint32_t max_abs() const { return (uint32_t)max(hi, -lo); }
+};
 template <int N> __device__ __forceinline__ uint32_t vec_max_abs(const int32_t *x) {
-    uint32_t m = 0;
+    HiLo m;
+    if constexpr (N % 2 == 0) {
 #pragma unroll
-    for (int i = 0; i < N; i++) m = max(m, (uint32_t)(x[i] < 0 ? -x[i] : x[i]));
-    return m;
+        for (int i = 0; i < N; i += 2) m.take(x[i], x[i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) m.take(x[i]);
+    }
+    return m.max_abs();
 }
 template <int N> __device__ __forceinline__ void shift_vec(int32_t *x, int sh) { // svt_av1_round_shift_array_c(x, N, -sh)
     if (sh < 0) {
@@ -442,6 +455,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     typedef Pix __attribute__((ext_vector_type(RUN), aligned(sizeof(Pix)))) RunU;
     uint32_t rmax = 0; // largest |residual| this lane produced
     {
+        HiLo rhl;
         // a lane's runs are fetched kResidualAhead at a time, all of a group in flight before the first is used (the loop's trip count depends
         // on the lane: left to itself every run is a round trip of its own)
         constexpr int NIT = (RPR * H + LW - 1) / LW, kResidualAhead = NIT < SVT_RD_RESIDUAL_AHEAD ? NIT : SVT_RD_RESIDUAL_AHEAD;
@@ -465,11 +479,12 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
                     for (int k = 0; k < RUN; k++) {
                         const int32_t d = (int16_t)((int16_t)sv[j][k] - (int16_t)pv[j][k]);
                         A[r * PA + c + k] = d;
-                        rmax = max(rmax, (uint32_t)(d < 0 ? -d : d));
+                        rhl.take(d);
                     }
                 }
             }
         }
+        rmax = rhl.max_abs();
     }
     // one answer for the wave (all its blocks): every residual small enough for the 24-bit multiplies of the forward passes?
     // one answer for the wave (all its blocks): small enough data for the three-instruction butterflies?  The column pass sees the residual
@@ -487,7 +502,8 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         shift_vec<H>(x, fsh[1]);
         const int oc = lr ? W - 1 - l : l;
 #pragma unroll
-        for (int r = 0; r < H; r++) { A[r * PA + oc] = x[r]; cmax = max(cmax, (uint32_t)(x[r] < 0 ? -x[r] : x[r])); }
+        for (int r = 0; r < H; r++) A[r * PA + oc] = x[r];
+        cmax = vec_max_abs<H>(x);
     }
     const bool fast_row = pass_fits_17_bits((uint32_t)__builtin_amdgcn_readfirstlane((int)seg_max_u32<64>(cmax)), W); // the row pass's input
     __syncthreads();
