@@ -78,6 +78,7 @@ __device__ __forceinline__ int32_t clampv(i64 v, int bit) {
     const i64 hi = ((i64)1 << (bit - 1)) - 1, lo = -((i64)1 << (bit - 1));
     return (int32_t)(v < lo ? lo : (v > hi ? hi : v));
 }
+__device__ __forceinline__ int32_t clampv(int32_t v, int bit) { return clamp32(v, bit); } // a 32-bit value against a range of at most 32 bits: the same number
 __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 
@@ -347,10 +348,12 @@ template <int N> __device__ __forceinline__ uint32_t vec_max_abs(const int32_t *
     }
     return m.max_abs();
 }
-template <int N> __device__ __forceinline__ void shift_vec(int32_t *x, int sh) { // svt_av1_round_shift_array_c(x, N, -sh)
+// SAFE32: the caller knows |x| < 2^30 (a pass that took the bounded butterflies, or an inverse pass, whose outputs are clamped to <= 18 bits):
+// the rounding add cannot wrap and the reference's 64-bit round_shift is the same two 32-bit instructions
+template <int N, bool SAFE32 = false> __device__ __forceinline__ void shift_vec(int32_t *x, int sh) { // svt_av1_round_shift_array_c(x, N, -sh)
     if (sh < 0) {
 #pragma unroll
-        for (int i = 0; i < N; i++) x[i] = rshift64(x[i], -sh);
+        for (int i = 0; i < N; i++) x[i] = SAFE32 ? ((x[i] + (1 << (-sh - 1))) >> -sh) : rshift64(x[i], -sh);
     } else if (sh > 0) {
 #pragma unroll
         for (int i = 0; i < N; i++) x[i] = (int32_t)((uint32_t)x[i] << sh);
@@ -432,6 +435,7 @@ __host__ __device__ constexpr int rd_waves_per_simd(int ts) {
 template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_simd(TS)) rd_tx_kernel(const RdParams p) {
     constexpr int W = tx_wide(TS), H = tx_high(TS), WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
     constexpr int LW = rd_lanes_per_block(TS), BPW = rd_blocks_per_wave(TS);
+    constexpr bool kShift32 = LW != 32; // bounded passes round-shift in 32 bits (measured: 64x64 -4 %; the 32-lane layout, at its 128-register limit, spills on it: +12 %)
     constexpr int PA = W + 1, PB = WP + 1; // row pitches (dwords) of the full block and of the packed coefficients
     constexpr int ROW_CLAMP = BD == 8 ? 16 : 18, COL_CLAMP = 16; // svt_av1_gen_inv_stage_range, inv_transforms.c:42-80
     constexpr bool RECT = (W == 2 * H || H == 2 * W);
@@ -498,8 +502,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
 #pragma unroll
         for (int r = 0; r < H; r++) x[r] = A[(ud ? H - 1 - r : r) * PA + l];
         shift_vec<H>(x, fsh[0]);
-        if (fast_col) fwd_1d<H, 2>(x, vt, bit_col); else fwd_1d<H, 0>(x, vt, bit_col); // wave-uniform
-        shift_vec<H>(x, fsh[1]);
+        if (fast_col) { fwd_1d<H, 2>(x, vt, bit_col); shift_vec<H, kShift32>(x, fsh[1]); } else { fwd_1d<H, 0>(x, vt, bit_col); shift_vec<H>(x, fsh[1]); } // wave-uniform
         const int oc = lr ? W - 1 - l : l;
 #pragma unroll
         for (int r = 0; r < H; r++) A[r * PA + oc] = x[r];
@@ -513,8 +516,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
         int32_t x[W];
 #pragma unroll
         for (int c = 0; c < W; c++) x[c] = A[l * PA + c];
-        if (fast_row) fwd_1d<W, 2>(x, ht, bit_row); else fwd_1d<W, 0>(x, ht, bit_row);
-        shift_vec<W>(x, fsh[2]);
+        if (fast_row) { fwd_1d<W, 2>(x, ht, bit_row); shift_vec<W, kShift32>(x, fsh[2]); } else { fwd_1d<W, 0>(x, ht, bit_row); shift_vec<W>(x, fsh[2]); }
         if constexpr (RECT) {
 #pragma unroll
             for (int c = 0; c < W; c++) x[c] = rshift64((i64)x[c] * 5793, 12);
@@ -712,7 +714,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
     uint32_t icmax = 0; // largest |row-pass output|: the column pass's input
     if (l < H) {
         if (fast_irow) inv_1d<W, ROW_CLAMP, 2>(xr, ht); else inv_1d<W, ROW_CLAMP, 1>(xr, ht);
-        shift_vec<W>(xr, c_inv_shift0[TS]);
+        shift_vec<W, kShift32>(xr, c_inv_shift0[TS]);
 #pragma unroll
         for (int c = 0; c < W; c++) A[l * PA + c] = xr[c];
         icmax = vec_max_abs<W>(xr);
@@ -727,7 +729,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
 #pragma unroll
         for (int r = 0; r < H; r++) x[r] = (r < HP) ? clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16) : 0; // rows >= 32 of a 64-row block are exactly zero after the row pass: constants, so the network prunes itself
         if (fast_icol) inv_1d<H, COL_CLAMP, 2>(x, vt); else inv_1d<H, COL_CLAMP, 1>(x, vt);
-        shift_vec<H>(x, -4);
+        shift_vec<H, kShift32>(x, -4);
         // residual (with the vertical flip undone) back to LDS, row-major: the reconstruction below moves whole runs
 #pragma unroll
         for (int r = 0; r < H; r++) A[r * PA + l] = x[ud ? H - 1 - r : r];
@@ -792,6 +794,7 @@ struct InvParams {
 template <int TS, int BD, typename Pix> __global__ void __launch_bounds__(64, rd_waves_per_simd(TS)) inv_tx_kernel(const InvParams p) {
     constexpr int W = tx_wide(TS), H = tx_high(TS), WP = W > 32 ? 32 : W, HP = H > 32 ? 32 : H, NP = WP * HP;
     constexpr int LW = rd_lanes_per_block(TS), BPW = rd_blocks_per_wave(TS);
+    constexpr bool kShift32 = LW != 32;
     constexpr int PA = W + 1, PB = WP + 1;
     constexpr int ROW_CLAMP = BD == 8 ? 16 : 18, COL_CLAMP = 16;
     constexpr bool RECT = (W == 2 * H || H == 2 * W);
@@ -822,7 +825,7 @@ template <int TS, int BD, typename Pix> __global__ void __launch_bounds__(64, rd
     uint32_t icmax = 0; // largest |row-pass output|: the column pass's input
     if (l < H) {
         if (fast_irow) inv_1d<W, ROW_CLAMP, 2>(xr, ht); else inv_1d<W, ROW_CLAMP, 1>(xr, ht);
-        shift_vec<W>(xr, c_inv_shift0[TS]);
+        shift_vec<W, kShift32>(xr, c_inv_shift0[TS]);
 #pragma unroll
         for (int c = 0; c < W; c++) A[l * PA + c] = xr[c];
         icmax = vec_max_abs<W>(xr);
@@ -835,7 +838,7 @@ template <int TS, int BD, typename Pix> __global__ void __launch_bounds__(64, rd
 #pragma unroll
         for (int r = 0; r < H; r++) x[r] = (r < HP) ? clampv(A[r * PA + ic], BD + 6 > 16 ? BD + 6 : 16) : 0;
         if (fast_icol) inv_1d<H, COL_CLAMP, 2>(x, vt); else inv_1d<H, COL_CLAMP, 1>(x, vt);
-        shift_vec<H>(x, -4);
+        shift_vec<H, kShift32>(x, -4);
 #pragma unroll
         for (int r = 0; r < H; r++) A[r * PA + l] = x[ud ? H - 1 - r : r];
     }
