@@ -762,8 +762,7 @@ template <int TS, int BD> __global__ void __launch_bounds__(64, rd_waves_per_sim
                     v = v < 0 ? 0 : (v > (1 << BD) - 1 ? (1 << BD) - 1 : v);
                     out[k] = (Pix)v;
                     const int e = (int)sv[it][k] - v;
-                    const uint32_t ue = (uint32_t)(e < 0 ? -e : e);
-                    sse += (u64)(ue * ue); // |e| < 2^16: the square fits 32 bits
+                    sse += (u64)((uint32_t)e * (uint32_t)e); // |e| < 2^16: the low 32 bits of the (wrapping) product are the square, whatever the sign
                 }
                 if (rec) *reinterpret_cast<RunU *>(rec + (size_t)r * p.d.pred_stride + c) = out;
             }
