@@ -24,7 +24,10 @@
 
 namespace {
 
-constexpr int kDenseTargetGroups = 384; // (octets x search rows x source rows) a lane aims for per unit
+#ifndef SVT_HIP_ME_DENSE_GROUPS
+#define SVT_HIP_ME_DENSE_GROUPS 384
+#endif
+constexpr int kDenseTargetGroups = SVT_HIP_ME_DENSE_GROUPS; // (octets x search rows x source rows) a lane aims for per unit (measured on the bench launch: 256 -> 0.553 ms, 384 -> 0.527, 768 -> 0.547)
 
 __device__ __forceinline__ u64 dense_group(const uint32_t (&wv)[6], const uint32_t (&s)[4], u64 acc, int half) {
     // 4 pixels x 4 dwords of one source row against the lane's octet: positions 0..3 (half 0) or 4..7 (half 1)
